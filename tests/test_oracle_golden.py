@@ -1,0 +1,92 @@
+"""CPU: pin the oracle (oracle/tld_oracle.c) and the host schedule against golden vectors captured
+from the reference (oracle/gen_golden.py).  Tolerances from SURVEY.md section 8c: fp32 restatement
+vs fp32 reference -- max-abs <= 1e-4 / rel-rms <= 1e-5 for one forward, <= 1e-3 / 1e-4 after a
+multi-step trajectory."""
+import numpy as np
+import pytest
+
+from conftest import cfg_from_arr, load_golden, max_abs, rel_rms, synth_weights
+from oracle.oracle import OracleDenoiser
+from transformer_latent_diffusion_amd import schedule
+
+
+def _model(g):
+    cfg = cfg_from_arr(g["cfg"])
+    sd = synth_weights(cfg, g["weight_seed"], g["weight_checksum"])
+    return cfg, OracleDenoiser(cfg, sd)
+
+
+def test_g1_tiny32_forward_and_stages():
+    g = load_golden("g1_tiny32_forward.npz")
+    cfg, m = _model(g)
+    out, st = m.forward(g["x"], g["sigma"], g["label"], debug=True)
+    for k in ("sin_emb", "cond_y", "tokens0", "blk0_sa", "blk0_ca", "blk0_mlp", "tokens_final", "x0"):
+        # sin/cos of phases up to ~6e3 rad: float32 argument rounding differs by <=1 ulp of the phase
+        tol = 2e-3 if k == "sin_emb" else 1e-4
+        assert max_abs(st[k], g[k]) <= tol * max(1.0, float(np.abs(g[k]).max())), k
+        assert rel_rms(st[k], g[k]) <= (1e-3 if k == "sin_emb" else 1e-5), (k, rel_rms(st[k], g[k]))
+    assert out.shape == g["x"].shape
+
+
+@pytest.mark.parametrize("name", ["g3_tiny16_forward.npz", "g4_wide1_forward.npz"])
+def test_forward_fixtures(name):
+    g = load_golden(name)
+    cfg, m = _model(g)
+    out = m(g["x"], g["sigma"], g["label"])
+    assert out.shape == g["x0"].shape
+    assert max_abs(out, g["x0"]) <= 1e-4 and rel_rms(out, g["x0"]) <= 1e-5, (max_abs(out, g["x0"]), rel_rms(out, g["x0"]))
+
+
+def test_g5_100m_forward():
+    g = load_golden("g5_100m.npz")
+    cfg, m = _model(g)
+    out = m(g["x"], g["sigma"], g["label"])
+    assert max_abs(out, g["x0"]) <= 1e-4 and rel_rms(out, g["x0"]) <= 1e-5, (max_abs(out, g["x0"]), rel_rms(out, g["x0"]))
+
+
+@pytest.mark.parametrize("tag,plus", [("dpm", True), ("ddim", False)])
+def test_g2_sampler_trajectory(tag, plus):
+    g = load_golden("g2_tiny32_sampler.npz")
+    cfg, m = _model(g)
+    levels = schedule.noise_schedule(int(g["n_iter"]), 1.0)
+    assert np.array_equal(np.array(levels), g["noise_levels"])
+    lat, tx0, txt = m.sample(g["seeds"], g["labels"], levels, float(g["class_guidance"]), plus,
+                             float(g["sharp_f"]), float(g["bright_f"]), trace=True)
+    # per-step CFG-combined predictions and states (golden xt[i] is the input of forward i)
+    n = len(levels)
+    for i in range(n - 1):
+        assert max_abs(tx0[i], g[f"{tag}_x0"][i]) <= 1e-3, i
+        assert max_abs(txt[i], g[f"{tag}_xt"][i + 1]) <= 1e-3, i
+    assert max_abs(lat, g[f"{tag}_latent"]) <= 1e-3
+    assert rel_rms(lat, g[f"{tag}_latent"]) <= 1e-4
+
+
+def test_g6_schedule_known_answers():
+    g = load_golden("g6_schedule.npz")
+    for n_iter, ex in g["cases"]:
+        n_iter = int(n_iter); ex = float(ex) if ex != int(ex) else int(ex)
+        tag = f"n{n_iter}_e{str(ex).replace('.', 'p')}"
+        levels = schedule.noise_schedule(n_iter, ex)
+        assert np.array_equal(np.array(levels, np.float64), g[tag + "_levels"]), tag
+        if tag + "_raises_zerodiv" in g:
+            with pytest.raises(ZeroDivisionError):
+                schedule.multistep_ratios(levels)
+        else:
+            rs = schedule.multistep_ratios(levels)
+            assert np.array_equal(np.array(rs, np.float64), g[tag + "_rs"]), tag
+
+
+def test_step_coefficients_match_reference_algebra():
+    g = load_golden("g2_tiny32_sampler.npz")
+    levels = [float(v) for v in g["noise_levels"]]
+    tab = schedule.step_coefficients(levels, True)
+    rs = g["rs"]
+    assert tab.shape == (len(levels), 6)
+    assert tab[0, 4] == 1.0 and tab[0, 5] == 0.0
+    for i in range(1, len(levels) - 1):
+        assert tab[i, 4] == np.float32(1 + 1 / (2 * rs[i - 1]))
+        assert tab[i, 5] == np.float32(1 / (2 * rs[i - 1]))
+        assert tab[i, 1] == np.float32(levels[i] - levels[i + 1])
+    assert tab[-1, 0] == np.float32(levels[-1])
+    ddim = schedule.step_coefficients(levels, False)
+    assert np.all(ddim[:, 4] == 1.0) and np.all(ddim[:, 5] == 0.0)
