@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- images/s of 256 px, 35-step CFG sampling on the 100M-parameter denoiser (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full pass of the hot path over one batch: DiffusionGenerator.generate_latents of
+64 images per GPU (32x32x4 latents, n_iter = 35, class_guidance = 6, DPM-Solver++(2M)): 35 CFG-doubled
+denoiser forwards of batch 128 + on-device CFG/solver updates (+ one all-gather of the final latents
+when N > 1).  Inputs (weights, initial noise, text embeddings) are resident in HBM before the timed
+region.  Weak scaling: 64 images per GPU.  Synthetic, seeded data: there is no network for the
+published checkpoint, so weights are the deterministic synthetic 101 M-parameter fill.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel class (by HIP-event time inside the timed region) against the
+                2.5 PFLOP/s dense bf16 MFMA peak
+  cpu_baseline  the CPU oracle (fp32 C restatement, all host cores) on a bounded sample of the same
+                workload -- a reported baseline, never part of the measured path
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+PER_GPU_IMAGES = 64
+N_ITER = 35
+CFG = 6.0
+GFLOP_PER_SAMPLE_FWD = 46.163      # SURVEY.md Appendix B (N=256, d=768, L=12), reference op count
+MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def gemm_flops(cls, M, d):
+    n, k = {"gemm_qkv": (3 * d, d), "gemm_up": (4 * d, d), "gemm_down": (d, 4 * d)}[cls]
+    return 2.0 * M * n * k
+
+
+def cpu_baseline(cfg, sd, budget_images=4, denoise_steps=4):
+    """Oracle (port) on the host cores: `denoise_steps` CFG steps of `budget_images` image(s), scaled to 35."""
+    from oracle.oracle import OracleDenoiser, num_threads
+    from transformer_latent_diffusion_amd import schedule
+    ora = OracleDenoiser(cfg, sd)
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((budget_images, 4, 32, 32)).astype(np.float32)
+    lab = (rng.standard_normal((budget_images, 768)) * 0.5).astype(np.float32)
+    levels = schedule.noise_schedule(N_ITER, 1)[: denoise_steps]          # first levels of the real schedule
+    ora.sample(x, lab, levels[:2], CFG, True, 0.0, 0.0)                    # warm (page in, pack)
+    t0 = time.perf_counter()
+    ora.sample(x, lab, levels, CFG, True, 0.0, 0.0)                        # `denoise_steps` CFG-doubled forwards
+    dt = time.perf_counter() - t0
+    per_step = dt / denoise_steps
+    img_s = budget_images / (per_step * N_ITER)
+    return {
+        "value": img_s, "unit": "images/s", "cores": num_threads(), "kind": "port",
+        "sample": f"{denoise_steps} of {N_ITER} CFG denoise steps on {budget_images} image(s) (batch {2 * budget_images}"
+                  f" forwards), fp32 C oracle with OpenMP; {per_step * 1e3:.0f} ms/step scaled to {N_ITER} steps",
+        "ms_per_denoise_step": per_step * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--images-per-gpu", type=int, default=PER_GPU_IMAGES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of the GEMM classes")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
+    assert torch.cuda.is_available(), "bench.py measures the HIP engine; no HIP device is visible"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dataclasses import asdict
+    from transformer_latent_diffusion_amd import Denoiser, DiffusionGenerator, config_100m
+    from transformer_latent_diffusion_amd.sharded import generate_latents_sharded
+    from transformer_latent_diffusion_amd.weights import synth_state_dict
+
+    cfg = config_100m()
+    sd = synth_state_dict(cfg, 5)
+    model = Denoiser(**asdict(cfg)).to(dev)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    B = args.images_per_gpu
+    model.reserve(2 * B)
+    gen = DiffusionGenerator(model, None, dev, torch.float32)
+
+    total = B * world
+    g = torch.Generator().manual_seed(11)
+    x_T = torch.randn(total, 4, 32, 32, generator=g).to(dev)                # resident before timing
+    labels = (torch.randn(total, 768, generator=torch.Generator().manual_seed(12)) * 0.5).to(dev)
+
+    def one_step():
+        return generate_latents_sharded(gen, labels, n_iter=N_ITER, num_imgs=total, class_guidance=CFG,
+                                        img_size=32, sharp_f=0.0, bright_f=0.0, exponent=1, seeds=x_T)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        out = one_step()
+    fence()
+    gemm_classes = ("gemm_qkv", "gemm_up", "gemm_down")
+    if not args.no_profile:
+        model.set_profile(gemm_classes)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    prof = {}
+    if not args.no_profile:
+        for c in gemm_classes:
+            ms, n = model.get_profile(c)
+            prof[c] = (ms, n)
+        model.set_profile(())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total * args.steps / dt
+        line = {
+            "metric": "images/sec (256px, 35-step CFG sampling), denoiser only",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "C1: 100M-param denoiser (d=768, L=12), 32x32x4 latents, 35 steps + CFG 6, "
+                                   f"DPM-Solver++(2M), {B} images/GPU (model batch {2 * B})",
+                       "images_per_gpu": B, "global_batch": total, "n_iter": N_ITER, "class_guidance": CFG,
+                       "parallelism": f"dp{world} (sample-sharded, one all-gather)" if world > 1 else "single GPU"},
+            "ms_per_denoise_step": ms_per_step / N_ITER,
+            "model_tflops": value * 2 * N_ITER * GFLOP_PER_SAMPLE_FWD / 1e3,
+            "frac_of_bf16_mfma_peak": value * 2 * N_ITER * GFLOP_PER_SAMPLE_FWD / 1e3 / (MFMA_PEAK_TFLOPS * world),
+        }
+        if prof:
+            M = 2 * B * 256
+            dom = max(prof, key=lambda c: prof[c][0])
+            ms, n = prof[dom]
+            avg_s = ms / max(n, 1) / 1e3
+            ach = gemm_flops(dom, M, cfg.embed_dim) / avg_s / 1e12
+            tot_f = sum(gemm_flops(c, M, cfg.embed_dim) * prof[c][1] for c in prof)
+            tot_t = sum(prof[c][0] for c in prof) / 1e3
+            line["roofline"] = {
+                "bound": "mfma", "kernel": f"gemm_bf16_kernel<{dom}>", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                "avg_launch_ms": ms / max(n, 1), "launches": n,
+                "flops_per_launch": gemm_flops(dom, M, cfg.embed_dim),
+                "all_gemm_classes": {c: {"avg_ms": prof[c][0] / max(prof[c][1], 1), "launches": prof[c][1],
+                                         "tflops": gemm_flops(c, M, cfg.embed_dim) / (prof[c][0] / max(prof[c][1], 1) / 1e3) / 1e12}
+                                     for c in prof},
+                "gemm_share_of_step_time": tot_t / dt, "gemm_aggregate_tflops": tot_f / tot_t / 1e12,
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

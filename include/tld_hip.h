@@ -1,0 +1,122 @@
+/*
+ * tld_hip.h -- C ABI of libtld_hip.so: the MI355X (gfx950) denoising engine.
+ *
+ * The reference has no FFI/plugin interface; its boundary is the Python nn.Module call contract
+ * between the sampler and the model.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference checkout).  Signatures use plain
+ * pointers and sizes only (no torch types): device buffers belong to the caller (PyTorch), packed
+ * weights and workspace belong to the engine.  All kernels are enqueued on the caller's HIP stream
+ * with no hidden synchronisation.  Every function returns 0 on success or a non-zero status;
+ * tld_last_error() returns the thread-local message.  Nothing throws across this boundary.
+ */
+#ifndef TLD_HIP_H
+#define TLD_HIP_H
+
+#include <stdint.h>
+
+#if defined(__GNUC__)
+#define TLD_API __attribute__((visibility("default")))
+#else
+#define TLD_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tld_engine tld_engine;
+
+/* Mirrors tld/configs.py:21-31 DenoiserConfig (dropout is identity at inference and not carried),
+ * plus engine sizing.  Replaces the kwargs of Denoiser.__init__ (tld/denoiser.py:86-97). */
+typedef struct tld_config {
+    int32_t image_size;
+    int32_t noise_embed_dims;
+    int32_t patch_size;
+    int32_t embed_dim;        /* multiple of 128, <= 1024: heads = embed_dim / 64, head_dim = 64 */
+    int32_t n_layers;
+    int32_t text_emb_size;
+    int32_t n_channels;
+    int32_t mlp_multiplier;
+    int32_t max_batch;        /* largest model batch (CFG-doubled) a forward will see */
+    int32_t device_id;        /* HIP device ordinal */
+} tld_config;
+
+enum { TLD_DTYPE_F32 = 0, TLD_DTYPE_BF16 = 1, TLD_DTYPE_F16 = 2 };
+
+enum {
+    TLD_OK = 0,
+    TLD_ERR_INVALID = 1,      /* bad argument / unsupported configuration */
+    TLD_ERR_KEY = 2,          /* unknown state_dict key */
+    TLD_ERR_SHAPE = 3,        /* tensor shape does not match the configuration */
+    TLD_ERR_STATE = 4,        /* call order (weights not finalized, missing tensors) */
+    TLD_ERR_HIP = 5           /* a HIP runtime call failed */
+};
+
+/* Denoiser(**asdict(cfg)) -- tld/denoiser.py:85-114, tld/diffusion.py:145 */
+TLD_API int tld_engine_create(const tld_config* cfg, tld_engine** out);
+
+/* Denoiser.load_state_dict, one entry at a time -- tld/diffusion.py:152-153.
+ * key is the reference state_dict key; host_ptr is contiguous host memory of `dtype`
+ * (TLD_DTYPE_F32; int64 buffers such as precomputed_pos_enc are passed with ndim/shape and ignored). */
+TLD_API int tld_engine_load_tensor(tld_engine* e, const char* key, const void* host_ptr, const int64_t* shape,
+                           int32_t ndim, int32_t dtype);
+
+/* Packs weights into device layouts (bf16 GEMM operands, folded tables).  Must follow the loads;
+ * fails with TLD_ERR_STATE and names the first missing key if the state_dict was incomplete. */
+TLD_API int tld_engine_finalize_weights(tld_engine* e);
+
+/* Denoiser.forward(x, noise_level, label) -- tld/denoiser.py:116-126 (called at tld/diffusion.py:97-101).
+ *   x      [batch, C, S, S]     device, io_dtype
+ *   noise  [batch, 1]           device, io_dtype
+ *   label  [batch, text_emb]    device, io_dtype
+ *   out    [batch, C, S, S]     device, io_dtype (may not alias x)
+ * Inputs are not modified. */
+TLD_API int tld_denoiser_forward(tld_engine* e, const void* x, const void* noise, const void* label, void* out,
+                         int32_t batch, int32_t io_dtype, void* hip_stream);
+
+/* DiffusionGenerator.generate minus RNG and VAE decode -- tld/diffusion.py:54-92 with pred_image
+ * (:94-103) and apply_classifier_free_guidance (:122-125) fused on device.
+ *   x_T     [batch, C, S, S] fp32 device: initial noise (initialize_image, :105-120, done by caller)
+ *   labels  [batch, text_emb] fp32 device: conditional embeddings only; the zero "uncond" half of
+ *           :61 is implicit
+ *   coeffs  [n_levels, 6] fp32 HOST: (sigma, a, b, c, c1, c2) per forward, see
+ *           transformer_latent_diffusion_amd/schedule.py (host float64 algebra of :50-57,:72-81)
+ *   out_latent [batch, C, S, S] fp32 device: x0_pred incl. sharp_f/bright_f shifts (:88-89)
+ *   trace_x0 / trace_xt: optional device buffers [n_levels-1, batch, C, S, S] fp32 (NULL to skip)
+ * batch*2 must be <= max_batch.  The call synchronises the stream once, before the first step,
+ * after uploading its host-built tables; the steps themselves are enqueued asynchronously. */
+TLD_API int tld_sample(tld_engine* e, const void* x_T, const void* labels, const float* coeffs, int32_t n_levels,
+               float class_guidance, float sharp_f, float bright_f, void* out_latent, int32_t batch,
+               void* trace_x0, void* trace_xt, void* hip_stream);
+
+/* Test hook: copy a named internal stage of the LAST forward to host fp32 (synchronises).
+ * names: "cond_y" [T,d] (T = batch noise rows then batch label rows), "tokens0", "blk0_sa",
+ * "blk0_ca", "blk0_mlp", "tokens_final" (each [batch*N, d]).  Stage capture must have been
+ * enabled with tld_engine_set_debug(e, 1) before the forward. */
+TLD_API int tld_engine_set_debug(tld_engine* e, int32_t enable);
+TLD_API int tld_engine_read_stage(tld_engine* e, const char* name, float* host_out, int64_t numel);
+
+/* Test hook: C[M,N] = A[M,K] . W[N,K]^T with the engine's bf16 MFMA GEMM (fp32 accumulate), bf16
+ * device inputs, fp32 device output.  K % 64 == 0. */
+TLD_API int tld_debug_gemm_bf16(const void* a_bf16, const void* w_bf16, float* c_f32, int32_t M, int32_t N,
+                        int32_t K, void* hip_stream);
+
+/* Live per-kernel-class timing with HIP events recorded on the launch stream around every launch
+ * of the selected classes (bit k of class_mask).  Classes: 0 gemm_qkv, 1 gemm_up, 2 gemm_down,
+ * 3 attention, 4 cross_row, 5 dwconv_gelu, 6 layernorm, 7 embed, 8 tail, 9 update, 10 conditioning.
+ * set_profile clears previously recorded events; get_profile synchronises the device and returns
+ * the summed elapsed time and the number of launches of one class since set_profile. */
+TLD_API int tld_engine_set_profile(tld_engine* e, uint32_t class_mask);
+TLD_API int tld_engine_get_profile(tld_engine* e, int32_t kclass, double* total_ms, int64_t* launches);
+
+/* bytes of packed weights resident on the device */
+TLD_API int64_t tld_engine_weight_bytes(const tld_engine* e);
+
+TLD_API int tld_engine_destroy(tld_engine* e);
+
+TLD_API const char* tld_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TLD_HIP_H */

@@ -195,54 +195,68 @@ TLD_O_EXPORT int tld_o_set_tensor(tld_o_model *m, const char *key, const float *
 /* ------------------------------------------------------------------------------------------ */
 
 /* out[M,N] = x[M,K] . W[N,K]^T (+ b[N]); nn.Linear semantics; W row-major like the state_dict.
- * W is transposed once per call into [K][Npad]; a 6x16 register tile then runs k sequentially
- * (one fp32 accumulation chain per output, k ascending) with 8-wide vector FMAs. */
+ * W is repacked once per call into 16-column panels [N/16][K][16]; blocks of 96 rows are distributed
+ * over threads and each (row block, panel) pair runs a 6x16 register tile with k ascending -- one
+ * fp32 accumulation chain per output element, 8-wide vector FMAs. */
 typedef float v8f __attribute__((vector_size(32), aligned(4)));
 #define MR 6
 #define NR 16
 static void linear(const float *x, const float *W, const float *b, int M, int K, int N, float *out) {
-    int Np = (N + NR - 1) / NR * NR;
-    float *Wt = (float *)aligned_alloc(64, ((size_t)K * Np * sizeof(float) + 63) / 64 * 64);
-    if (!Wt) abort();
+    int npan = (N + NR - 1) / NR;
+    float *Wp = (float *)aligned_alloc(64, ((size_t)npan * K * NR * sizeof(float) + 63) / 64 * 64);
+    if (!Wp) abort();
 #pragma omp parallel for schedule(static)
-    for (int k = 0; k < K; ++k) {
-        float *row = Wt + (size_t)k * Np;
-        for (int n = 0; n < N; ++n) row[n] = W[(size_t)n * K + k];
-        for (int n = N; n < Np; ++n) row[n] = 0.f;
-    }
-    int mblocks = (M + MR - 1) / MR;
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int mb = 0; mb < mblocks; ++mb) {
-        int m0 = mb * MR;
-        const float *xr[MR];
-        for (int i = 0; i < MR; ++i) {
-            int r = m0 + i < M ? m0 + i : M - 1;           /* clamp: duplicate rows are not stored */
-            xr[i] = x + (size_t)r * K;
+    for (int pn = 0; pn < npan; ++pn) {
+        float *dst = Wp + (size_t)pn * K * NR;
+        for (int j = 0; j < NR; ++j) {
+            int n = pn * NR + j;
+            if (n < N) for (int k = 0; k < K; ++k) dst[(size_t)k * NR + j] = W[(size_t)n * K + k];
+            else for (int k = 0; k < K; ++k) dst[(size_t)k * NR + j] = 0.f;
         }
-        for (int n0 = 0; n0 < Np; n0 += NR) {
-            v8f acc[MR][2];
-            for (int i = 0; i < MR; ++i) { acc[i][0] = (v8f){0}; acc[i][1] = (v8f){0}; }
-            const float *wp = Wt + n0;
-            for (int k = 0; k < K; ++k) {
-                v8f b0 = *(const v8f *)(wp + (size_t)k * Np);
-                v8f b1 = *(const v8f *)(wp + (size_t)k * Np + 8);
+    }
+    int nthr = 1;
+#ifdef _OPENMP
+    nthr = omp_get_max_threads();
+#endif
+    int MB = (M / (2 * nthr)) / MR * MR;          /* >= 2 row blocks per thread when M allows */
+    if (MB > 96) MB = 96;
+    if (MB < MR) MB = MR;
+    int mblocks = (M + MB - 1) / MB;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int mb = 0; mb < mblocks; ++mb) {
+        int mlo = mb * MB, mhi = mlo + MB < M ? mlo + MB : M;
+        for (int pn = 0; pn < npan; ++pn) {
+            const float *wp = Wp + (size_t)pn * K * NR;
+            int n0 = pn * NR;
+            for (int m0 = mlo; m0 < mhi; m0 += MR) {
+                const float *xr[MR];
                 for (int i = 0; i < MR; ++i) {
-                    float a = xr[i][k];
-                    v8f av = {a, a, a, a, a, a, a, a};
-                    acc[i][0] += av * b0;
-                    acc[i][1] += av * b1;
+                    int r = m0 + i < mhi ? m0 + i : mhi - 1;   /* clamp: duplicate rows are not stored */
+                    xr[i] = x + (size_t)r * K;
+                }
+                v8f acc[MR][2];
+                for (int i = 0; i < MR; ++i) { acc[i][0] = (v8f){0}; acc[i][1] = (v8f){0}; }
+                for (int k = 0; k < K; ++k) {
+                    v8f b0 = *(const v8f *)(wp + (size_t)k * NR);
+                    v8f b1 = *(const v8f *)(wp + (size_t)k * NR + 8);
+                    for (int i = 0; i < MR; ++i) {
+                        float a = xr[i][k];
+                        v8f av = {a, a, a, a, a, a, a, a};
+                        acc[i][0] += av * b0;
+                        acc[i][1] += av * b1;
+                    }
+                }
+                for (int i = 0; i < MR && m0 + i < mhi; ++i) {
+                    float tmp[NR];
+                    *(v8f *)tmp = acc[i][0]; *(v8f *)(tmp + 8) = acc[i][1];
+                    float *o = out + (size_t)(m0 + i) * N + n0;
+                    int lim = N - n0 < NR ? N - n0 : NR;
+                    for (int j = 0; j < lim; ++j) o[j] = tmp[j] + (b ? b[n0 + j] : 0.f);
                 }
             }
-            for (int i = 0; i < MR && m0 + i < M; ++i) {
-                float tmp[NR];
-                *(v8f *)tmp = acc[i][0]; *(v8f *)(tmp + 8) = acc[i][1];
-                float *o = out + (size_t)(m0 + i) * N + n0;
-                int lim = N - n0 < NR ? N - n0 : NR;
-                for (int j = 0; j < lim; ++j) o[j] = tmp[j] + (b ? b[n0 + j] : 0.f);
-            }
         }
     }
-    free(Wt);
+    free(Wp);
 }
 
 /* nn.LayerNorm: biased variance, eps 1e-5, affine (Appendix A of SURVEY.md) */

@@ -1,0 +1,107 @@
+"""CPU: host-side mirror of the reference interface (configs, Denoiser facade, sampler shell, grid)."""
+from dataclasses import asdict, fields
+
+import numpy as np
+import pytest
+import torch
+
+from transformer_latent_diffusion_amd import (ClipConfig, Denoiser, DenoiserConfig, DenoiserLoad, DiffusionGenerator,
+                                              LTDConfig, VaeConfig, config_100m, schedule)
+from transformer_latent_diffusion_amd.diffusion import make_image_grid, to_pil
+from transformer_latent_diffusion_amd.sharded import shard_bounds
+from transformer_latent_diffusion_amd.weights import param_count, state_dict_spec
+
+
+def test_config_surface_matches_reference_fields():
+    # tld/configs.py:21-31, :33-37, :39-43, :45-48, :75-81
+    assert [f.name for f in fields(DenoiserConfig)] == ["image_size", "noise_embed_dims", "patch_size", "embed_dim",
+                                                        "dropout", "n_layers", "text_emb_size", "n_channels",
+                                                        "mlp_multiplier"]
+    assert asdict(DenoiserConfig()) == dict(image_size=16, noise_embed_dims=256, patch_size=2, embed_dim=128,
+                                            dropout=0, n_layers=3, text_emb_size=768, n_channels=4, mlp_multiplier=4)
+    dl = DenoiserLoad()
+    assert dl.dtype == torch.float32 and dl.file_url is None and dl.local_filename is None
+    assert VaeConfig().vae_scale_factor == 8 and VaeConfig().vae_name == "madebyollin/sdxl-vae-fp16-fix"
+    assert ClipConfig().clip_model_name == "ViT-L/14" and ClipConfig().clip_dtype == torch.float16
+    c = LTDConfig()
+    assert isinstance(c.denoiser_cfg, DenoiserConfig) and isinstance(c.vae_cfg, VaeConfig)
+    assert [f.name for f in fields(LTDConfig)] == ["denoiser_cfg", "denoiser_load", "vae_cfg", "clip_cfg"]
+
+
+def test_param_counts():
+    assert param_count(DenoiserConfig()) == 868800
+    assert param_count(DenoiserConfig(image_size=32, n_channels=4)) == 893376
+    assert param_count(config_100m()) == 101164352
+
+
+def test_denoiser_facade_contract():
+    cfg = DenoiserConfig(n_channels=4)
+    m = Denoiser(**asdict(cfg))
+    assert m.n_channels == 4 and m.image_size == 16
+    assert m.eval() is m and m.to(torch.float32) is m and m.to(torch.device("cpu")) is m
+    assert sum(p.numel() for p in m.parameters()) == 868800
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(state_dict_spec(cfg).keys())
+    assert sd["denoiser_trans_block.precomputed_pos_enc"].dtype == torch.int64
+    m.load_state_dict(sd)
+    bad = dict(sd); bad.pop("norm.weight")
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    bad = dict(sd); bad["norm.weight"] = torch.zeros(7)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    bad = dict(sd); bad["extra.key"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    with pytest.raises(RuntimeError):                                     # no CPU path, fail loudly
+        m(torch.zeros(2, 4, 16, 16), torch.zeros(2, 1), torch.zeros(2, 768))
+    with pytest.raises(NotImplementedError):
+        m.train()
+
+
+def test_generator_shell_without_gpu_fails_loudly_and_checks_labels():
+    cfg = DenoiserConfig(n_channels=4)
+    gen = DiffusionGenerator(Denoiser(**asdict(cfg)), None, torch.device("cpu"), torch.float32)
+    x = gen.initialize_image(None, 3, 16, seed=10)
+    ref = torch.randn(3, 4, 16, 16, generator=torch.Generator().manual_seed(10))
+    assert torch.equal(x, ref)                                           # diffusion.py:108-118 on cpu
+    s = torch.ones(2, 4, 16, 16, dtype=torch.float64)
+    assert gen.initialize_image(s, 2, 16, 0).dtype == torch.float32      # seeds.to(device, model_dtype)
+    with pytest.raises(RuntimeError):
+        gen.generate(torch.zeros(2, 768), num_imgs=3, img_size=16, n_iter=5)   # labels/num_imgs mismatch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            gen.generate(torch.zeros(3, 768), num_imgs=3, img_size=16, n_iter=5)
+
+
+def test_schedule_edge_cases():
+    lv = schedule.noise_schedule(35, 1)
+    assert len(lv) == 35 and lv[0] == 0.99 and lv[-1] == pytest.approx(1 - 34 / 35, abs=1e-6)
+    assert len(schedule.noise_schedule(49, 1)) == 50                     # arange float-step quirk
+    with pytest.raises(ZeroDivisionError):
+        schedule.step_coefficients(schedule.noise_schedule(49, 1), True)
+    custom = schedule.noise_schedule(3, 1, noise_levels=[0.5, 0.4, 0.2])
+    assert custom == [0.99, 0.4, 0.2]                                    # [0] is always overwritten (:52)
+    with pytest.raises(UnboundLocalError):
+        schedule.step_coefficients([0.99], True)
+    tab = schedule.step_coefficients([0.99, 0.5], True)                  # two levels: no multistep ratio needed
+    assert tab.shape == (2, 6) and tab[0, 4] == 1 and tab[0, 5] == 0
+
+
+def test_image_grid_and_pil():
+    imgs = torch.rand(5, 3, 8, 8)
+    grid = make_image_grid(imgs, nrow=2, padding=4)
+    assert grid.shape == (3, 3 * 12 + 4, 2 * 12 + 4)
+    assert torch.equal(grid[:, 4:12, 4:12], imgs[0]) and torch.equal(grid[:, 16:24, 16:24], imgs[3])
+    assert make_image_grid(imgs[:1], nrow=1).shape == (3, 8, 8)
+    assert to_pil(grid).size == (28, 40)
+
+
+def test_shard_bounds_cover_exactly():
+    for total in (0, 1, 7, 64, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,84 @@
+"""ctypes binding of libtld_hip.so (the C ABI declared in include/tld_hip.h).
+
+The library is built in-tree by ``csrc/Makefile`` (``__graft_entry__.build()``).  There is no
+fallback: if the shared object is missing or a call fails, a RuntimeError carrying
+``tld_last_error()`` is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtld_hip.so")
+
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+
+KERNEL_CLASSES = ("gemm_qkv", "gemm_up", "gemm_down", "attention", "cross_row", "dwconv_gelu", "layernorm",
+                  "embed", "tail", "update", "conditioning")
+
+# every symbol include/tld_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = (
+    "tld_engine_create", "tld_engine_load_tensor", "tld_engine_finalize_weights", "tld_denoiser_forward",
+    "tld_sample", "tld_engine_set_debug", "tld_engine_read_stage", "tld_debug_gemm_bf16",
+    "tld_engine_set_profile", "tld_engine_get_profile", "tld_engine_weight_bytes", "tld_engine_destroy",
+    "tld_last_error",
+)
+
+
+class TldConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("image_size", "noise_embed_dims", "patch_size", "embed_dim", "n_layers",
+                                         "text_emb_size", "n_channels", "mlp_multiplier", "max_batch",
+                                         "device_id")]
+
+
+_lib = None
+
+
+def build(verbose: bool = False) -> None:
+    """Compile libtld_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    import subprocess
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode:
+        print(r.stdout)
+    if r.returncode:
+        raise RuntimeError("building libtld_hip.so failed")
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C transformer_latent_diffusion_amd/csrc`). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
+    L.tld_last_error.restype = C.c_char_p
+    L.tld_engine_create.argtypes = [C.POINTER(TldConfig), C.POINTER(vp)]
+    L.tld_engine_load_tensor.argtypes = [vp, C.c_char_p, vp, i64p, i32, i32]
+    L.tld_engine_finalize_weights.argtypes = [vp]
+    L.tld_denoiser_forward.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
+    L.tld_sample.argtypes = [vp, vp, vp, C.POINTER(C.c_float), i32, C.c_float, C.c_float, C.c_float, vp, i32,
+                             vp, vp, vp]
+    L.tld_engine_set_debug.argtypes = [vp, i32]
+    L.tld_engine_read_stage.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
+    L.tld_debug_gemm_bf16.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.tld_engine_set_profile.argtypes = [vp, C.c_uint32]
+    L.tld_engine_get_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.tld_engine_weight_bytes.argtypes = [vp]
+    L.tld_engine_weight_bytes.restype = C.c_int64
+    L.tld_engine_destroy.argtypes = [vp]
+    for name in ABI_SYMBOLS:
+        if name not in ("tld_last_error", "tld_engine_weight_bytes"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().tld_last_error()
+        raise RuntimeError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,140 @@
+// tld_common.h -- shared device/host declarations of the gfx950 denoising engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tld {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// Residual stream dtype.  fp32 keeps the 36 residual adds of a forward exact to fp32 rounding;
+// GEMM/attention operands are bf16 regardless.
+typedef float resid_t;
+
+constexpr int kWave = 64;
+constexpr int kHeadDim = 64;
+constexpr float kLnEps = 1e-5f;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ---- launch descriptors ------------------------------------------------------------------------
+
+enum GemmEpilogue {
+    EPI_F32 = 0,         // C fp32 [M,N]                         (debug / small tables)
+    EPI_QKV = 1,         // q,k -> bf16 [M,2d] ; v -> bf16 transposed per (sample, head): [B,H,64,Ntok]
+    EPI_BIAS_BF16 = 2,   // bf16(C + bias[n]) -> [M,N]           (MLP up projection)
+    EPI_BIAS_RESID = 3,  // x[m,n] += C + bias[n] (resid_t)      (MLP down projection)
+};
+
+struct GemmParams {
+    const bf16* A; int lda;       // [M,K] row-major, K contiguous
+    const bf16* W; int ldw;       // [N,K] row-major (nn.Linear weight layout)
+    int M, N, K;
+    float* c_f32; int ldc;        // EPI_F32
+    bf16* out_bf16; int ldo;      // EPI_QKV (q|k, ldo = 2d) / EPI_BIAS_BF16
+    bf16* vt;                     // EPI_QKV
+    int ntok, d;                  // EPI_QKV
+    const float* bias;            // EPI_BIAS_*
+    resid_t* resid; int ldr;      // EPI_BIAS_RESID
+};
+
+void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s);
+
+// self-attention over ntok tokens, head_dim 64: softmax(q k^T / 8) v -> att bf16 [M, d]
+void launch_attention(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads,
+                      hipStream_t s);
+
+// depthwise 3x3 (zero pad) + bias + exact GELU on channels-last [B, g, g, C] bf16
+void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c /*[9][C]*/, const float* bias,
+                        int batch, int grid, int channels, hipStream_t s);
+
+struct EmbedParams {
+    const float* x;               // [B,C,S,S] fp32
+    const float* conv_w;          // [pd, C*p*p]
+    const float* conv_b;          // [pd]
+    const float* ln1_w; const float* ln1_b;   // [pd]
+    const float* lin_wt;          // [pd, d]  (transposed nn.Linear weight)
+    const float* lin_b;           // [d]
+    const float* ln2_w; const float* ln2_b;   // [d]
+    const float* pos;             // [N, d]
+    resid_t* tok;                 // [B*N, d]
+    int batch, src_batch;         // model sample b reads latent b % src_batch (CFG doubling without a copy)
+    int C, S, p, grid, pd, d, ntok;
+};
+void launch_embed(const EmbedParams& p, hipStream_t s);
+
+// LayerNorm rows: x [M,d] -> bf16 normalized-affine [M,d]
+void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf16* out, int M, int d,
+                           hipStream_t s);
+
+// Fused row kernel of one decoder block's middle:
+//   x += att (self-attention residual);  cross-attention to the 2 conditioning tokens computed from
+//   row statistics and per-sample folded query vectors;  x += cross;  xn3 = LN3(x) in bf16.
+struct CrossRowParams {
+    resid_t* x;                   // [M,d] in/out
+    const bf16* att;              // [M,d]
+    const float* wq;              // [T, H, d]  gamma2 * (Wq_h^T k_t[h] / 8) for this layer (per token row)
+    const float* bwq;             // [T, H]     sum_j beta2[j] * (Wq_h^T k_t[h] / 8)[j]
+    const float* v; int v_ld;     // [T, v_ld]  cross-attention values (per token row) for this layer
+    const int* noise_row;         // [B] token row of each sample's noise token
+    const int* label_row;         // [B] token row of each sample's label token
+    const float* ln2_w; const float* ln2_b;
+    const float* ln3_w; const float* ln3_b;
+    bf16* xn3;                    // [M,d]
+    float* sa_out;                // optional debug dump of x + att  [M,d]
+    int batch, ntok, d, heads;
+};
+void launch_cross_row(const CrossRowParams& p, hipStream_t s);
+
+struct TailParams {
+    const resid_t* tok;           // [B*N, d]
+    const float* w;               // [pd, d]
+    const float* b;               // [pd]
+    float* out;                   // [B,C,S,S] fp32
+    int batch, C, S, p, grid, pd, d, ntok;
+};
+void launch_tail(const TailParams& p, hipStream_t s);
+
+// sampler elementwise: CFG combine + multistep update (see schedule.py)
+struct UpdateParams {
+    const float* x0_2b;           // [2B, img] model output (cond rows first, then uncond)
+    float* x_t;                   // [B, img]  in/out
+    float* x0_prev;               // [B, img]  in/out
+    float* x0_out;                // [B, img]  CFG-combined prediction (always written)
+    float* trace_x0; float* trace_xt;  // optional [B, img]
+    float g, a, b, c, c1, c2, sharp, bright;
+    int final_step;               // 1: only combine (+shifts on channels 3 and 0), no update
+    int batch, img, chan_stride, C;
+};
+void launch_update(const UpdateParams& p, hipStream_t s);
+
+// ---- conditioning path (fp32) ------------------------------------------------------------------
+// out[t, n] = act(sum_k in[t,k] W[n,k] + b[n]);  act: 0 none, 1 exact GELU
+void launch_linear_f32(const float* in, int ldi, const float* W, const float* b, float* out, int ldo,
+                       int T, int K, int N, int act, hipStream_t s);
+void launch_sinusoid(const float* sigma, const float* angular, float* out, int T, int half, hipStream_t s);
+void launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int M, int d,
+                          hipStream_t s);
+// raw[t,h,j] = (1/8) sum_c k[t, h*64+c] Wq[h*64+c, j];  wq = raw * gamma[j];  bwq[t,h] = sum_j beta[j] raw
+void launch_wq(const float* k, int ldk, const float* Wq, const float* gamma, const float* beta, float* wq,
+               float* bwq, int T, int heads, int d, hipStream_t s);
+// dst_f32 <- src (fp32/bf16/f16) and back
+void launch_cast_to_f32(const void* src, int dtype, float* dst, int64_t n, hipStream_t s);
+void launch_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
+void launch_iota(int* dst, int n, int base, hipStream_t s);
+
+}  // namespace tld

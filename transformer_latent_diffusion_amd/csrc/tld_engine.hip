@@ -1,0 +1,608 @@
+// tld_engine.hip -- host side of libtld_hip.so: weight packing, workspace, kernel sequencing, C ABI.
+//
+// One engine = one device + one model.  The forward is a fixed sequence of hand-written kernels
+// (7 per decoder block) enqueued on the caller's stream; the sampler prepares every conditioning
+// table once (all timesteps, all prompts) and then runs embed -> blocks -> tail -> update per step
+// with no host round trip.  See DESIGN.md for the data layout and per-kernel roofline notes.
+#include "../../include/tld_hip.h"
+#include "tld_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace tld;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(TLD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+inline uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct Layer {
+    bf16 *qkv_w = nullptr, *up_w = nullptr, *down_w = nullptr;
+    float *up_b = nullptr, *dw_w9c = nullptr, *dw_b = nullptr, *down_b = nullptr;
+    float *n1_w = nullptr, *n1_b = nullptr, *n2_w = nullptr, *n2_b = nullptr, *n3_w = nullptr, *n3_b = nullptr;
+    float *kv_w = nullptr, *q_w = nullptr;   // fp32, conditioning path
+};
+
+enum KClass { KC_GEMM_QKV = 0, KC_GEMM_UP, KC_GEMM_DOWN, KC_ATTN, KC_CROSS, KC_DWCONV, KC_LN, KC_EMBED,
+              KC_TAIL, KC_UPDATE, KC_COND, KC_COUNT };
+
+}  // namespace
+
+struct tld_engine {
+    tld_config cfg{};
+    int d = 0, L = 0, H = 0, ntok = 0, grid = 0, pd = 0, hid = 0, img = 0, ne = 0, text = 0;
+    bool finalized = false;
+    std::map<std::string, HostTensor> host;
+    std::vector<void*> allocs;
+    int64_t weight_bytes = 0;
+
+    // fp32 parameters
+    float *angular = nullptr, *ff1_w = nullptr, *ff1_b = nullptr, *ff3_w = nullptr, *ff3_b = nullptr;
+    float *label_w = nullptr, *label_b = nullptr, *norm_w = nullptr, *norm_b = nullptr;
+    float *conv_w = nullptr, *conv_b = nullptr, *pln1_w = nullptr, *pln1_b = nullptr, *plin_wt = nullptr,
+          *plin_b = nullptr, *pln2_w = nullptr, *pln2_b = nullptr, *pos = nullptr, *out_w = nullptr,
+          *out_b = nullptr;
+    std::vector<Layer> layers;
+
+    // activations (sized for cfg.max_batch)
+    resid_t* x = nullptr;
+    bf16 *xn = nullptr, *qk = nullptr, *vt = nullptr, *att = nullptr, *hid1 = nullptr, *hid2 = nullptr;
+    float *io_x = nullptr, *io_sigma = nullptr, *io_label = nullptr, *io_out = nullptr;
+    float *xt = nullptr, *x0_prev = nullptr, *x0_cfg = nullptr;
+    int* rows_dev = nullptr;           // noise_row / label_row tables
+    int64_t rows_cap = 0;
+
+    // conditioning tables (sized for cond_cap token rows)
+    int cond_cap = 0;
+    float *c_sigma = nullptr, *c_sin = nullptr, *c_h1 = nullptr, *c_pre = nullptr, *c_y = nullptr,
+          *c_label = nullptr;
+    float *c_kv = nullptr;             // [L][T][2d]
+    float *c_wq = nullptr;             // [L][T][H][d]
+    float *c_bwq = nullptr;            // [L][T][H]
+
+    // debug stage capture
+    bool debug = false;
+    int dbg_batch = 0, dbg_T = 0;
+    std::map<std::string, float*> stages;
+
+    // per-class event profiling
+    uint32_t prof_mask = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[KC_COUNT];
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(tld_engine* e, T** p, size_t count) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, count * sizeof(T) + 256));
+    e->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return TLD_OK;
+}
+
+int upload_f32(tld_engine* e, const char* key, float** dst, int64_t expect) {
+    auto it = e->host.find(key);
+    if (it == e->host.end()) return fail(TLD_ERR_STATE, "state_dict entry missing: %s", key);
+    if ((int64_t)it->second.data.size() != expect)
+        return fail(TLD_ERR_SHAPE, "%s: expected %lld elements, got %lld", key, (long long)expect,
+                    (long long)it->second.data.size());
+    if (int rc = dev_alloc(e, dst, (size_t)expect)) return rc;
+    HIP_TRY(hipMemcpy(*dst, it->second.data.data(), expect * sizeof(float), hipMemcpyHostToDevice));
+    e->weight_bytes += expect * sizeof(float);
+    return TLD_OK;
+}
+
+int upload_bf16(tld_engine* e, const char* key, bf16** dst, int64_t expect) {
+    auto it = e->host.find(key);
+    if (it == e->host.end()) return fail(TLD_ERR_STATE, "state_dict entry missing: %s", key);
+    if ((int64_t)it->second.data.size() != expect)
+        return fail(TLD_ERR_SHAPE, "%s: expected %lld elements, got %lld", key, (long long)expect,
+                    (long long)it->second.data.size());
+    std::vector<uint16_t> tmp((size_t)expect);
+    const float* src = it->second.data.data();
+    for (int64_t i = 0; i < expect; ++i) tmp[(size_t)i] = f32_to_bf16_rne(src[i]);
+    if (int rc = dev_alloc(e, dst, (size_t)expect)) return rc;
+    HIP_TRY(hipMemcpy(*dst, tmp.data(), expect * 2, hipMemcpyHostToDevice));
+    e->weight_bytes += expect * 2;
+    return TLD_OK;
+}
+
+int ensure_cond_capacity(tld_engine* e, int T) {
+    if (T <= e->cond_cap) return TLD_OK;
+    // grow-only; old tables are kept in e->allocs and freed at destroy (growth happens at most a few times)
+    const int cap = ((T + 63) / 64) * 64;
+    const size_t d = e->d, L = e->L, H = e->H;
+    if (int rc = dev_alloc(e, &e->c_sigma, (size_t)cap)) return rc;
+    if (int rc = dev_alloc(e, &e->c_sin, (size_t)cap * e->ne)) return rc;
+    if (int rc = dev_alloc(e, &e->c_h1, (size_t)cap * d)) return rc;
+    if (int rc = dev_alloc(e, &e->c_pre, (size_t)cap * d)) return rc;
+    if (int rc = dev_alloc(e, &e->c_y, (size_t)cap * d)) return rc;
+    if (int rc = dev_alloc(e, &e->c_label, (size_t)cap * e->text)) return rc;
+    if (int rc = dev_alloc(e, &e->c_kv, L * cap * 2 * d)) return rc;
+    if (int rc = dev_alloc(e, &e->c_wq, L * cap * H * d)) return rc;
+    if (int rc = dev_alloc(e, &e->c_bwq, L * cap * H)) return rc;
+    e->cond_cap = cap;
+    return TLD_OK;
+}
+
+int ensure_rows_capacity(tld_engine* e, int64_t n) {
+    if (n <= e->rows_cap) return TLD_OK;
+    if (int rc = dev_alloc(e, &e->rows_dev, (size_t)n)) return rc;
+    e->rows_cap = n;
+    return TLD_OK;
+}
+
+struct ProfScope {
+    tld_engine* e; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(tld_engine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_) {
+        on = (e->prof_mask >> cls) & 1u;
+        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+    }
+    ~ProfScope() {
+        if (on) { hipEventRecord(b, s); e->prof_ev[cls].emplace_back(a, b); }
+    }
+};
+
+int capture(tld_engine* e, const char* name, const float* src, size_t count, hipStream_t s) {
+    if (!e->debug) return TLD_OK;
+    float*& buf = e->stages[name];
+    if (!buf) {
+        const size_t cap = (size_t)std::max(e->cfg.max_batch * e->ntok, 4 * e->cfg.max_batch + 1024) * e->d;
+        if (int rc = dev_alloc(e, &buf, cap)) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(buf, src, count * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return TLD_OK;
+}
+
+// Conditioning tables for T token rows whose pre-LN vectors sit in c_pre[0..T): y = LN(pre), then per
+// layer K|V = y Wkv^T and the folded query vectors (denoiser.py:121-122, transformer_blocks.py:65-71).
+int cond_tables(tld_engine* e, int T, hipStream_t s) {
+    const int d = e->d;
+    ProfScope ps(e, KC_COND, s);
+    launch_layernorm_f32(e->c_pre, e->norm_w, e->norm_b, e->c_y, T, d, s);
+    for (int l = 0; l < e->L; ++l) {
+        const Layer& Ly = e->layers[l];
+        float* kv = e->c_kv + (size_t)l * e->cond_cap * 2 * d;
+        launch_linear_f32(e->c_y, d, Ly.kv_w, nullptr, kv, 2 * d, T, d, 2 * d, 0, s);
+        launch_wq(kv, 2 * d, Ly.q_w, Ly.n2_w, Ly.n2_b, e->c_wq + (size_t)l * e->cond_cap * e->H * d,
+                  e->c_bwq + (size_t)l * e->cond_cap * e->H, T, e->H, d, s);
+    }
+    return TLD_OK;
+}
+
+// noise rows: sigma[0..Tn) in c_sigma -> c_pre[0..Tn)   (denoiser.py:105-110,117)
+void cond_noise_rows(tld_engine* e, int Tn, hipStream_t s) {
+    launch_sinusoid(e->c_sigma, e->angular, e->c_sin, Tn, e->ne / 2, s);
+    launch_linear_f32(e->c_sin, e->ne, e->ff1_w, e->ff1_b, e->c_h1, e->d, Tn, e->ne, e->d, 1, s);
+    launch_linear_f32(e->c_h1, e->d, e->ff3_w, e->ff3_b, e->c_pre, e->d, Tn, e->d, e->d, 0, s);
+}
+
+// label rows: c_label[0..Tl) -> c_pre[row0 .. row0+Tl)   (denoiser.py:114,119)
+void cond_label_rows(tld_engine* e, int row0, int Tl, hipStream_t s) {
+    launch_linear_f32(e->c_label, e->text, e->label_w, e->label_b, e->c_pre + (size_t)row0 * e->d, e->d, Tl,
+                      e->text, e->d, 0, s);
+}
+
+// embed -> L decoder blocks -> tail, for `batch` model samples whose latents are x_src[b % src_batch].
+int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const int* noise_row,
+             const int* label_row, float* out, hipStream_t s) {
+    const int d = e->d, M = batch * e->ntok;
+    {
+        ProfScope ps(e, KC_EMBED, s);
+        EmbedParams ep{};
+        ep.x = x_src; ep.conv_w = e->conv_w; ep.conv_b = e->conv_b; ep.ln1_w = e->pln1_w; ep.ln1_b = e->pln1_b;
+        ep.lin_wt = e->plin_wt; ep.lin_b = e->plin_b; ep.ln2_w = e->pln2_w; ep.ln2_b = e->pln2_b; ep.pos = e->pos;
+        ep.tok = e->x; ep.batch = batch; ep.src_batch = src_batch; ep.C = e->cfg.n_channels;
+        ep.S = e->cfg.image_size; ep.p = e->cfg.patch_size; ep.grid = e->grid; ep.pd = e->pd; ep.d = d;
+        ep.ntok = e->ntok;
+        launch_embed(ep, s);
+    }
+    if (int rc = capture(e, "tokens0", e->x, (size_t)M * d, s)) return rc;
+    for (int l = 0; l < e->L; ++l) {
+        const Layer& Ly = e->layers[l];
+        {   // xn = LN1(x)
+            ProfScope ps(e, KC_LN, s);
+            launch_layernorm_bf16(e->x, Ly.n1_w, Ly.n1_b, e->xn, M, d, s);
+        }
+        {   // q|k, v^T = xn Wqkv^T
+            ProfScope ps(e, KC_GEMM_QKV, s);
+            GemmParams g{};
+            g.A = e->xn; g.lda = d; g.W = Ly.qkv_w; g.ldw = d; g.M = M; g.N = 3 * d; g.K = d;
+            g.out_bf16 = e->qk; g.ldo = 2 * d; g.vt = e->vt; g.ntok = e->ntok; g.d = d;
+            launch_gemm(g, EPI_QKV, s);
+        }
+        {
+            ProfScope ps(e, KC_ATTN, s);
+            launch_attention(e->qk, e->vt, e->att, batch, e->ntok, e->H, s);
+        }
+        if (l == 0 && e->debug && !e->stages["blk0_sa"]) {
+            float* buf = nullptr;
+            if (int rc = dev_alloc(e, &buf, (size_t)e->cfg.max_batch * e->ntok * d)) return rc;
+            e->stages["blk0_sa"] = buf;
+        }
+        {   // x += att; x += CA(LN2 x, y); xn = LN3(x)
+            ProfScope ps(e, KC_CROSS, s);
+            CrossRowParams cp{};
+            cp.x = e->x; cp.att = e->att;
+            cp.wq = e->c_wq + (size_t)l * e->cond_cap * e->H * d;
+            cp.bwq = e->c_bwq + (size_t)l * e->cond_cap * e->H;
+            cp.v = e->c_kv + (size_t)l * e->cond_cap * 2 * d + d;     // V half of each [2d] row
+            cp.v_ld = 2 * d;
+            cp.noise_row = noise_row; cp.label_row = label_row;
+            cp.ln2_w = Ly.n2_w; cp.ln2_b = Ly.n2_b; cp.ln3_w = Ly.n3_w; cp.ln3_b = Ly.n3_b;
+            cp.xn3 = e->xn; cp.batch = batch; cp.ntok = e->ntok; cp.d = d; cp.heads = e->H;
+            cp.sa_out = (l == 0 && e->debug) ? e->stages["blk0_sa"] : nullptr;
+            launch_cross_row(cp, s);
+        }
+        if (l == 0) if (int rc = capture(e, "blk0_ca", e->x, (size_t)M * d, s)) return rc;
+        {   // hid1 = xn Wup^T + b
+            ProfScope ps(e, KC_GEMM_UP, s);
+            GemmParams g{};
+            g.A = e->xn; g.lda = d; g.W = Ly.up_w; g.ldw = d; g.M = M; g.N = e->hid; g.K = d;
+            g.out_bf16 = e->hid1; g.ldo = e->hid; g.bias = Ly.up_b;
+            launch_gemm(g, EPI_BIAS_BF16, s);
+        }
+        {
+            ProfScope ps(e, KC_DWCONV, s);
+            launch_dwconv_gelu(e->hid1, e->hid2, Ly.dw_w9c, Ly.dw_b, batch, e->grid, e->hid, s);
+        }
+        {   // x += hid2 Wdown^T + b
+            ProfScope ps(e, KC_GEMM_DOWN, s);
+            GemmParams g{};
+            g.A = e->hid2; g.lda = e->hid; g.W = Ly.down_w; g.ldw = e->hid; g.M = M; g.N = d; g.K = e->hid;
+            g.bias = Ly.down_b; g.resid = e->x; g.ldr = d;
+            launch_gemm(g, EPI_BIAS_RESID, s);
+        }
+        if (l == 0) if (int rc = capture(e, "blk0_mlp", e->x, (size_t)M * d, s)) return rc;
+    }
+    if (int rc = capture(e, "tokens_final", e->x, (size_t)M * d, s)) return rc;
+    {
+        ProfScope ps(e, KC_TAIL, s);
+        TailParams tp{};
+        tp.tok = e->x; tp.w = e->out_w; tp.b = e->out_b; tp.out = out; tp.batch = batch;
+        tp.C = e->cfg.n_channels; tp.S = e->cfg.image_size; tp.p = e->cfg.patch_size; tp.grid = e->grid;
+        tp.pd = e->pd; tp.d = d; tp.ntok = e->ntok;
+        launch_tail(tp, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* tld_last_error(void) { return g_err; }
+
+int tld_engine_create(const tld_config* c, tld_engine** out) {
+    if (!c || !out) return fail(TLD_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (c->embed_dim <= 0 || c->embed_dim % 128 != 0 || c->embed_dim > 1024)
+        return fail(TLD_ERR_INVALID, "embed_dim=%d unsupported: must be a multiple of 128, <= 1024 "
+                    "(head_dim is 64 and row kernels own 128-feature groups)", c->embed_dim);
+    if (c->patch_size <= 0 || c->image_size % c->patch_size != 0)
+        return fail(TLD_ERR_INVALID, "image_size=%d must be divisible by patch_size=%d", c->image_size, c->patch_size);
+    const int grid = c->image_size / c->patch_size, ntok = grid * grid;
+    if (!(ntok == 32 || ntok == 64 || ntok == 128 || ntok % 256 == 0))
+        return fail(TLD_ERR_INVALID, "token count %d unsupported (need 32, 64, 128 or a multiple of 256)", ntok);
+    const int pd = c->n_channels * c->patch_size * c->patch_size;
+    if (pd > 64) return fail(TLD_ERR_INVALID, "patch_dim=%d > 64 unsupported", pd);
+    if (c->noise_embed_dims % 2 || c->noise_embed_dims <= 0) return fail(TLD_ERR_INVALID, "noise_embed_dims must be even");
+    if (c->max_batch <= 0 || c->n_layers <= 0 || c->mlp_multiplier <= 0 || c->text_emb_size <= 0)
+        return fail(TLD_ERR_INVALID, "non-positive size in config");
+    if ((c->mlp_multiplier * c->embed_dim) % 64) return fail(TLD_ERR_INVALID, "hidden width must be a multiple of 64");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (c->device_id < 0 || c->device_id >= ndev) return fail(TLD_ERR_INVALID, "device_id %d out of range (%d devices)", c->device_id, ndev);
+    HIP_TRY(hipSetDevice(c->device_id));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(TLD_ERR_INVALID, "device %d is %s; this engine is built for gfx950 only", c->device_id, prop.gcnArchName);
+    tld_engine* e = new tld_engine();
+    e->cfg = *c;
+    e->d = c->embed_dim; e->L = c->n_layers; e->H = c->embed_dim / 64; e->grid = grid; e->ntok = ntok;
+    e->pd = pd; e->hid = c->mlp_multiplier * c->embed_dim; e->img = c->n_channels * c->image_size * c->image_size;
+    e->ne = c->noise_embed_dims; e->text = c->text_emb_size;
+    e->layers.resize(e->L);
+    *out = e;
+    return TLD_OK;
+}
+
+int tld_engine_load_tensor(tld_engine* e, const char* key, const void* host_ptr, const int64_t* shape,
+                           int32_t ndim, int32_t dtype) {
+    if (!e || !key || (!host_ptr && ndim > 0)) return fail(TLD_ERR_INVALID, "null argument");
+    if (e->finalized) return fail(TLD_ERR_STATE, "weights already finalized");
+    if (strstr(key, "precomputed_pos_enc")) return TLD_OK;          // arange buffer (denoiser.py:55)
+    if (dtype != TLD_DTYPE_F32) return fail(TLD_ERR_INVALID, "%s: only fp32 state_dict tensors are accepted", key);
+    int64_t n = 1;
+    HostTensor t;
+    for (int i = 0; i < ndim; ++i) { n *= shape[i]; t.shape.push_back(shape[i]); }
+    t.data.assign(static_cast<const float*>(host_ptr), static_cast<const float*>(host_ptr) + n);
+    e->host[key] = std::move(t);
+    return TLD_OK;
+}
+
+int tld_engine_finalize_weights(tld_engine* e) {
+    if (!e) return fail(TLD_ERR_INVALID, "null engine");
+    if (e->finalized) return TLD_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device_id));
+    const int64_t d = e->d, ne = e->ne, pd = e->pd, hid = e->hid, N = e->ntok, text = e->text;
+    const int64_t cpp = pd;   // C*p*p
+#define UP32(key, field, n) if (int rc = upload_f32(e, key, &e->field, (n))) return rc;
+    UP32("fourier_feats.0.angular_speeds", angular, ne / 2)
+    UP32("fourier_feats.1.weight", ff1_w, d * ne) UP32("fourier_feats.1.bias", ff1_b, d)
+    UP32("fourier_feats.3.weight", ff3_w, d * d) UP32("fourier_feats.3.bias", ff3_b, d)
+    UP32("label_proj.weight", label_w, d * text) UP32("label_proj.bias", label_b, d)
+    UP32("norm.weight", norm_w, d) UP32("norm.bias", norm_b, d)
+    UP32("denoiser_trans_block.patchify_and_embed.0.weight", conv_w, pd * cpp)
+    UP32("denoiser_trans_block.patchify_and_embed.0.bias", conv_b, pd)
+    UP32("denoiser_trans_block.patchify_and_embed.2.weight", pln1_w, pd)
+    UP32("denoiser_trans_block.patchify_and_embed.2.bias", pln1_b, pd)
+    UP32("denoiser_trans_block.patchify_and_embed.3.bias", plin_b, d)
+    UP32("denoiser_trans_block.patchify_and_embed.4.weight", pln2_w, d)
+    UP32("denoiser_trans_block.patchify_and_embed.4.bias", pln2_b, d)
+    UP32("denoiser_trans_block.pos_embed.weight", pos, N * d)
+    UP32("denoiser_trans_block.out_proj.0.weight", out_w, pd * d)
+    UP32("denoiser_trans_block.out_proj.0.bias", out_b, pd)
+#undef UP32
+    {   // Linear(pd -> d) weight [d, pd] -> transposed [pd, d] for coalesced per-feature reads
+        const char* key = "denoiser_trans_block.patchify_and_embed.3.weight";
+        auto it = e->host.find(key);
+        if (it == e->host.end()) return fail(TLD_ERR_STATE, "state_dict entry missing: %s", key);
+        if ((int64_t)it->second.data.size() != d * pd) return fail(TLD_ERR_SHAPE, "%s: bad size", key);
+        std::vector<float> tr((size_t)(d * pd));
+        for (int64_t n = 0; n < d; ++n)
+            for (int64_t o = 0; o < pd; ++o) tr[(size_t)(o * d + n)] = it->second.data[(size_t)(n * pd + o)];
+        if (int rc = dev_alloc(e, &e->plin_wt, (size_t)(d * pd))) return rc;
+        HIP_TRY(hipMemcpy(e->plin_wt, tr.data(), tr.size() * sizeof(float), hipMemcpyHostToDevice));
+        e->weight_bytes += (int64_t)tr.size() * 4;
+    }
+    char key[256];
+    for (int l = 0; l < e->L; ++l) {
+        Layer& Ly = e->layers[l];
+#define LK(suffix) (snprintf(key, sizeof(key), "denoiser_trans_block.decoder_blocks.%d.%s", l, suffix), key)
+        if (int rc = upload_bf16(e, LK("self_attention.qkv_linear.weight"), &Ly.qkv_w, 3 * d * d)) return rc;
+        if (int rc = upload_f32(e, LK("cross_attention.kv_linear.weight"), &Ly.kv_w, 2 * d * d)) return rc;
+        if (int rc = upload_f32(e, LK("cross_attention.q_linear.weight"), &Ly.q_w, d * d)) return rc;
+        if (int rc = upload_bf16(e, LK("mlp.mlp.0.weight"), &Ly.up_w, hid * d)) return rc;
+        if (int rc = upload_f32(e, LK("mlp.mlp.0.bias"), &Ly.up_b, hid)) return rc;
+        if (int rc = upload_f32(e, LK("mlp.mlp.1.bias"), &Ly.dw_b, hid)) return rc;
+        if (int rc = upload_bf16(e, LK("mlp.mlp.3.weight"), &Ly.down_w, d * hid)) return rc;
+        if (int rc = upload_f32(e, LK("mlp.mlp.3.bias"), &Ly.down_b, d)) return rc;
+        if (int rc = upload_f32(e, LK("norm1.weight"), &Ly.n1_w, d)) return rc;
+        if (int rc = upload_f32(e, LK("norm1.bias"), &Ly.n1_b, d)) return rc;
+        if (int rc = upload_f32(e, LK("norm2.weight"), &Ly.n2_w, d)) return rc;
+        if (int rc = upload_f32(e, LK("norm2.bias"), &Ly.n2_b, d)) return rc;
+        if (int rc = upload_f32(e, LK("norm3.weight"), &Ly.n3_w, d)) return rc;
+        if (int rc = upload_f32(e, LK("norm3.bias"), &Ly.n3_b, d)) return rc;
+        {   // depthwise weight [hid,1,3,3] -> [9][hid]
+            auto it = e->host.find(LK("mlp.mlp.1.weight"));
+            if (it == e->host.end()) return fail(TLD_ERR_STATE, "state_dict entry missing: %s", key);
+            if ((int64_t)it->second.data.size() != hid * 9) return fail(TLD_ERR_SHAPE, "%s: bad size", key);
+            std::vector<float> tr((size_t)(hid * 9));
+            for (int64_t c = 0; c < hid; ++c)
+                for (int k = 0; k < 9; ++k) tr[(size_t)(k * hid + c)] = it->second.data[(size_t)(c * 9 + k)];
+            if (int rc = dev_alloc(e, &Ly.dw_w9c, (size_t)(hid * 9))) return rc;
+            HIP_TRY(hipMemcpy(Ly.dw_w9c, tr.data(), tr.size() * sizeof(float), hipMemcpyHostToDevice));
+            e->weight_bytes += (int64_t)tr.size() * 4;
+        }
+#undef LK
+    }
+    e->host.clear();
+
+    const size_t B2 = (size_t)e->cfg.max_batch, M = B2 * e->ntok;
+    if (int rc = dev_alloc(e, &e->x, M * d)) return rc;
+    if (int rc = dev_alloc(e, &e->xn, M * d)) return rc;
+    if (int rc = dev_alloc(e, &e->qk, M * 2 * d)) return rc;
+    if (int rc = dev_alloc(e, &e->vt, M * d)) return rc;
+    if (int rc = dev_alloc(e, &e->att, M * d)) return rc;
+    if (int rc = dev_alloc(e, &e->hid1, M * hid)) return rc;
+    if (int rc = dev_alloc(e, &e->hid2, M * hid)) return rc;
+    if (int rc = dev_alloc(e, &e->io_x, B2 * e->img)) return rc;
+    if (int rc = dev_alloc(e, &e->io_out, B2 * e->img)) return rc;
+    if (int rc = dev_alloc(e, &e->io_sigma, B2)) return rc;
+    if (int rc = dev_alloc(e, &e->io_label, B2 * e->text)) return rc;
+    if (int rc = dev_alloc(e, &e->xt, B2 * e->img)) return rc;
+    if (int rc = dev_alloc(e, &e->x0_prev, B2 * e->img)) return rc;
+    if (int rc = dev_alloc(e, &e->x0_cfg, B2 * e->img)) return rc;
+    if (int rc = ensure_cond_capacity(e, 2 * (int)B2)) return rc;
+    if (int rc = ensure_rows_capacity(e, 64 * (int64_t)B2)) return rc;
+    e->finalized = true;
+    return TLD_OK;
+}
+
+int tld_engine_set_debug(tld_engine* e, int32_t enable) {
+    if (!e) return fail(TLD_ERR_INVALID, "null engine");
+    e->debug = enable != 0;
+    return TLD_OK;
+}
+
+int tld_engine_read_stage(tld_engine* e, const char* name, float* host_out, int64_t numel) {
+    if (!e || !name || !host_out) return fail(TLD_ERR_INVALID, "null argument");
+    HIP_TRY(hipDeviceSynchronize());
+    const float* src = nullptr;
+    if (!strcmp(name, "cond_y")) src = e->c_y;
+    else {
+        auto it = e->stages.find(name);
+        if (it != e->stages.end()) src = it->second;
+    }
+    if (!src) return fail(TLD_ERR_KEY, "no captured stage named %s (was debug enabled before the forward?)", name);
+    HIP_TRY(hipMemcpy(host_out, src, numel * sizeof(float), hipMemcpyDeviceToHost));
+    return TLD_OK;
+}
+
+int tld_denoiser_forward(tld_engine* e, const void* x, const void* noise, const void* label, void* out,
+                         int32_t batch, int32_t io_dtype, void* hip_stream) {
+    if (!e || !x || !noise || !label || !out) return fail(TLD_ERR_INVALID, "null argument");
+    if (!e->finalized) return fail(TLD_ERR_STATE, "weights not finalized");
+    if (batch <= 0 || batch > e->cfg.max_batch) return fail(TLD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", batch, e->cfg.max_batch);
+    if (io_dtype < 0 || io_dtype > 2) return fail(TLD_ERR_INVALID, "bad io_dtype %d", io_dtype);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const float* xin = static_cast<const float*>(x);
+    float* o = static_cast<float*>(out);
+    if (io_dtype != TLD_DTYPE_F32) {
+        launch_cast_to_f32(x, io_dtype, e->io_x, (int64_t)batch * e->img, s);
+        xin = e->io_x; o = e->io_out;
+    }
+    // conditioning token rows: [0,batch) noise tokens, [batch, 2*batch) label tokens
+    launch_cast_to_f32(noise, io_dtype, e->c_sigma, batch, s);
+    launch_cast_to_f32(label, io_dtype, e->c_label, (int64_t)batch * e->text, s);
+    {
+        ProfScope ps(e, KC_COND, s);
+        cond_noise_rows(e, batch, s);
+        cond_label_rows(e, batch, batch, s);
+    }
+    if (int rc = cond_tables(e, 2 * batch, s)) return rc;
+    launch_iota(e->rows_dev, 2 * batch, 0, s);
+    e->dbg_batch = batch; e->dbg_T = 2 * batch;
+    if (int rc = run_body(e, xin, batch, batch, e->rows_dev, e->rows_dev + batch, o, s)) return rc;
+    if (io_dtype != TLD_DTYPE_F32) launch_cast_from_f32(e->io_out, out, io_dtype, (int64_t)batch * e->img, s);
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
+int tld_sample(tld_engine* e, const void* x_T, const void* labels, const float* coeffs, int32_t n_levels,
+               float class_guidance, float sharp_f, float bright_f, void* out_latent, int32_t batch,
+               void* trace_x0, void* trace_xt, void* hip_stream) {
+    if (!e || !x_T || !labels || !coeffs || !out_latent) return fail(TLD_ERR_INVALID, "null argument");
+    if (!e->finalized) return fail(TLD_ERR_STATE, "weights not finalized");
+    if (batch <= 0 || 2 * batch > e->cfg.max_batch)
+        return fail(TLD_ERR_INVALID, "sampler batch %d needs max_batch >= %d (have %d)", batch, 2 * batch, e->cfg.max_batch);
+    if (n_levels < 2) return fail(TLD_ERR_INVALID, "need at least two noise levels");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int B = batch, B2 = 2 * batch, T = n_levels + B + 1;
+    if (int rc = ensure_cond_capacity(e, T)) return rc;
+    if (int rc = ensure_rows_capacity(e, (int64_t)(n_levels + 1) * B2)) return rc;
+
+    // ---- conditioning tables for the whole trajectory, once
+    std::vector<float> sig((size_t)n_levels);
+    for (int i = 0; i < n_levels; ++i) sig[(size_t)i] = coeffs[(size_t)i * 6 + 0];
+    HIP_TRY(hipMemcpyAsync(e->c_sigma, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(e->c_label, labels, (size_t)B * e->text * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(e->c_label + (size_t)B * e->text, 0, e->text * sizeof(float), s));   // uncond = zeros (diffusion.py:61)
+    {
+        ProfScope ps(e, KC_COND, s);
+        cond_noise_rows(e, n_levels, s);
+        cond_label_rows(e, n_levels, B + 1, s);
+    }
+    if (int rc = cond_tables(e, T, s)) return rc;
+    // row tables: [step][B2] noise rows, then one [B2] label-row table
+    std::vector<int> rows((size_t)(n_levels + 1) * B2);
+    for (int i = 0; i < n_levels; ++i)
+        for (int b = 0; b < B2; ++b) rows[(size_t)i * B2 + b] = i;
+    for (int b = 0; b < B2; ++b) rows[(size_t)n_levels * B2 + b] = n_levels + (b < B ? b : B);
+    HIP_TRY(hipMemcpyAsync(e->rows_dev, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));    // host temporaries above must outlive their copies
+    const int* label_row = e->rows_dev + (size_t)n_levels * B2;
+
+    const size_t tot = (size_t)B * e->img;
+    HIP_TRY(hipMemcpyAsync(e->xt, x_T, tot * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(e->x0_prev, 0, tot * sizeof(float), s));
+    e->dbg_batch = B2; e->dbg_T = T;
+
+    for (int i = 0; i < n_levels; ++i) {
+        const bool final_step = (i == n_levels - 1);
+        // pred_image: model(cat[x_t, x_t], sigma_i, [labels; 0])   (diffusion.py:94-101)
+        if (int rc = run_body(e, e->xt, B, B2, e->rows_dev + (size_t)i * B2, label_row, e->io_out, s)) return rc;
+        ProfScope ps(e, KC_UPDATE, s);
+        UpdateParams up{};
+        const float* c = coeffs + (size_t)i * 6;
+        up.x0_2b = e->io_out; up.x_t = e->xt; up.x0_prev = e->x0_prev;
+        up.x0_out = final_step ? static_cast<float*>(out_latent) : e->x0_cfg;
+        up.trace_x0 = (!final_step && trace_x0) ? static_cast<float*>(trace_x0) + (size_t)i * tot : nullptr;
+        up.trace_xt = (!final_step && trace_xt) ? static_cast<float*>(trace_xt) + (size_t)i * tot : nullptr;
+        up.g = class_guidance; up.a = c[1]; up.b = c[2]; up.c = c[3]; up.c1 = c[4]; up.c2 = c[5];
+        up.sharp = sharp_f; up.bright = bright_f; up.final_step = final_step ? 1 : 0;
+        up.batch = B; up.img = e->img; up.chan_stride = e->cfg.image_size * e->cfg.image_size; up.C = e->cfg.n_channels;
+        launch_update(up, s);
+    }
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
+int tld_debug_gemm_bf16(const void* a, const void* w, float* c, int32_t M, int32_t N, int32_t K, void* hip_stream) {
+    if (!a || !w || !c) return fail(TLD_ERR_INVALID, "null argument");
+    if (K % 64 || K <= 0 || M <= 0 || N <= 0) return fail(TLD_ERR_INVALID, "need K %% 64 == 0 and positive sizes");
+    GemmParams g{};
+    g.A = static_cast<const bf16*>(a); g.lda = K; g.W = static_cast<const bf16*>(w); g.ldw = K;
+    g.M = M; g.N = N; g.K = K; g.c_f32 = c; g.ldc = N;
+    launch_gemm(g, EPI_F32, static_cast<hipStream_t>(hip_stream));
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
+int tld_engine_set_profile(tld_engine* e, uint32_t class_mask) {
+    if (!e) return fail(TLD_ERR_INVALID, "null engine");
+    for (int k = 0; k < KC_COUNT; ++k) {
+        for (auto& ev : e->prof_ev[k]) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+        e->prof_ev[k].clear();
+    }
+    e->prof_mask = class_mask;
+    return TLD_OK;
+}
+
+int tld_engine_get_profile(tld_engine* e, int32_t kclass, double* total_ms, int64_t* launches) {
+    if (!e || !total_ms || !launches) return fail(TLD_ERR_INVALID, "null argument");
+    if (kclass < 0 || kclass >= KC_COUNT) return fail(TLD_ERR_INVALID, "bad kernel class %d", kclass);
+    HIP_TRY(hipDeviceSynchronize());
+    double tot = 0.0;
+    for (auto& ev : e->prof_ev[kclass]) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int64_t)e->prof_ev[kclass].size();
+    return TLD_OK;
+}
+
+int64_t tld_engine_weight_bytes(const tld_engine* e) { return e ? e->weight_bytes : 0; }
+
+int tld_engine_destroy(tld_engine* e) {
+    if (!e) return TLD_OK;
+    (void)hipSetDevice(e->cfg.device_id);
+    (void)hipDeviceSynchronize();
+    for (int k = 0; k < KC_COUNT; ++k)
+        for (auto& ev : e->prof_ev[k]) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+    return TLD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+"""Sampler and pipeline surface: ``DiffusionGenerator`` and ``DiffusionTransformer``.
+
+Same signatures, defaults and return values as the reference (tld/diffusion.py:22-125, :143-186);
+the reverse-diffusion loop itself (CFG doubled batch, DPM-Solver++(2M) / DDIM update, final
+prediction, latent shifts) runs on the device inside ``tld_sample`` -- Python computes the float64
+schedule scalars (schedule.py), draws or accepts the initial noise, and hands off to the VAE at
+the exit edge.  CLIP and the VAE are third-party models outside the denoising path: they are injected
+(or imported lazily when installed) and never re-implemented here.
+"""
+from __future__ import annotations
+
+from dataclasses import asdict, dataclass
+from typing import Any, Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import schedule
+from .configs import LTDConfig
+from .denoiser import Denoiser
+
+device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+
+
+@dataclass
+class DiffusionGenerator:
+    model: Denoiser
+    vae: Any                      # object with .decode(latents) -> (image_tensor, ...); may be None
+    device: torch.device
+    model_dtype: torch.dtype = torch.float32
+
+    @torch.no_grad()
+    def generate(
+        self,
+        labels: Tensor,
+        n_iter: int = 30,
+        num_imgs: int = 16,
+        class_guidance: float = 3,
+        seed: int = 10,
+        scale_factor: int = 8,
+        img_size: int = 32,
+        sharp_f: float = 0.1,
+        bright_f: float = 0.1,
+        exponent: float = 1,
+        seeds: Optional[Tensor] = None,
+        noise_levels=None,
+        use_ddpm_plus: bool = True,
+    ):
+        """Reverse diffusion with classifier-free guidance; returns (decoded_images_on_cpu, latents).
+
+        ``use_ddpm_plus=True``: DPM-Solver++(2M); else DDIM with alpha = 1 - sigma (diffusion.py:45-48).
+        """
+        latents = self.generate_latents(labels, n_iter, num_imgs, class_guidance, seed, img_size, sharp_f,
+                                        bright_f, exponent, seeds, noise_levels, use_ddpm_plus)
+        if self.vae is None:
+            return None, latents
+        img = self.vae.decode((latents * scale_factor).to(self.model_dtype))[0].cpu()   # diffusion.py:91
+        return img, latents
+
+    @torch.no_grad()
+    def generate_latents(self, labels, n_iter=30, num_imgs=16, class_guidance=3, seed=10, img_size=32,
+                         sharp_f=0.1, bright_f=0.1, exponent=1, seeds=None, noise_levels=None,
+                         use_ddpm_plus=True, trace=False):
+        levels = schedule.noise_schedule(n_iter, exponent, noise_levels)
+        coeffs = schedule.step_coefficients(levels, use_ddpm_plus)
+        x_t = self.initialize_image(seeds, num_imgs, img_size, seed)
+        if labels.size(0) != x_t.size(0):
+            # the reference zips labels and noise by torch.cat (diffusion.py:61,98)
+            raise RuntimeError(f"labels batch {labels.size(0)} != num_imgs {x_t.size(0)}")
+        self.model.eval()
+        out = self.model.sample_latents(x_t, labels.to(self.device), coeffs, class_guidance, sharp_f, bright_f,
+                                        trace=trace)
+        if trace:
+            lat, tx0, txt = out
+            return lat.to(self.model_dtype), tx0, txt
+        return out.to(self.model_dtype)
+
+    def initialize_image(self, seeds, num_imgs, img_size, seed):
+        """Initial noise: a ``torch.Generator`` on ``self.device`` seeded with ``seed`` or the caller's
+        ``seeds`` tensor (diffusion.py:105-120)."""
+        if seeds is None:
+            generator = torch.Generator(device=self.device)
+            generator.manual_seed(seed)
+            return torch.randn(num_imgs, self.model.n_channels, img_size, img_size, dtype=self.model_dtype,
+                               device=self.device, generator=generator)
+        return seeds.to(self.device, self.model_dtype)
+
+
+def download_file(url, filename):
+    import requests
+    with requests.get(url, stream=True) as r:
+        r.raise_for_status()
+        with open(filename, "wb") as f:
+            for chunk in r.iter_content(chunk_size=8192):
+                f.write(chunk)
+
+
+def make_image_grid(images: Tensor, nrow: int, padding: int = 4) -> Tensor:
+    """[B,C,H,W] -> [C, rows*(H+pad)+pad, cols*(W+pad)+pad] grid with zero padding (the layout the
+    reference obtains from torchvision.utils.make_grid at diffusion.py:185)."""
+    b, c, h, w = images.shape
+    if b == 1:
+        return images[0]
+    cols = min(nrow, b)
+    rows = (b + cols - 1) // cols
+    grid = images.new_zeros((c, rows * (h + padding) + padding, cols * (w + padding) + padding))
+    for k in range(b):
+        r, q = divmod(k, cols)
+        y0, x0 = r * (h + padding) + padding, q * (w + padding) + padding
+        grid[:, y0:y0 + h, x0:x0 + w] = images[k]
+    return grid
+
+
+def to_pil(img: Tensor):
+    from PIL import Image
+    arr = (img.clamp(0, 1) * 255).to(torch.uint8).permute(1, 2, 0).cpu().numpy()
+    return Image.fromarray(arr.squeeze(-1) if arr.shape[-1] == 1 else arr)
+
+
+class DiffusionTransformer:
+    """Text -> image pipeline shell (diffusion.py:143-186).
+
+    ``vae`` / ``clip_model`` / ``text_encoder`` may be injected; otherwise ``diffusers`` and ``clip`` are
+    imported lazily exactly where the reference uses them and a missing package raises ImportError.
+    """
+
+    def __init__(self, cfg: LTDConfig, vae: Any = None, clip_model: Any = None, text_encoder=None,
+                 run_device: Optional[torch.device] = None):
+        dev = run_device if run_device is not None else device
+        denoiser = Denoiser(**asdict(cfg.denoiser_cfg))
+        denoiser = denoiser.to(cfg.denoiser_load.dtype)
+        if cfg.denoiser_load.file_url is not None and cfg.denoiser_load.local_filename is not None:
+            print(f"Downloading model from {cfg.denoiser_load.file_url}")
+            download_file(cfg.denoiser_load.file_url, cfg.denoiser_load.local_filename)
+            state_dict = torch.load(cfg.denoiser_load.local_filename, map_location=torch.device("cpu"))
+            denoiser.load_state_dict(state_dict)
+        denoiser = denoiser.to(dev)
+        if vae is None:
+            from diffusers import AutoencoderKL   # third-party exit edge
+            vae = AutoencoderKL.from_pretrained(cfg.vae_cfg.vae_name, torch_dtype=cfg.vae_cfg.vae_dtype).to(dev)
+        self._text_encoder = text_encoder
+        if clip_model is None and text_encoder is None:
+            import clip                            # third-party entry edge
+            clip_model, _ = clip.load(cfg.clip_cfg.clip_model_name)
+            clip_model = clip_model.to(dev)
+        self.clip_model = clip_model
+        self.device = dev
+        self.diffuser = DiffusionGenerator(denoiser, vae, dev, cfg.denoiser_load.dtype)
+
+    @torch.no_grad()
+    def encode_text(self, prompts):
+        if self._text_encoder is not None:
+            return self._text_encoder(prompts).cpu()
+        import clip
+        tokens = clip.tokenize(prompts, truncate=True).to(self.device)
+        return self.clip_model.encode_text(tokens).cpu()
+
+    def generate_image_from_text(self, prompt: str, class_guidance=6, seed=11, num_imgs=1, img_size=32, n_iter=15):
+        nrow = int(np.sqrt(num_imgs))
+        labels = self.encode_text([prompt] * num_imgs)
+        # NOTE: like the reference, ``img_size`` is ignored in favour of the model's own size (:175)
+        out, out_latent = self.diffuser.generate(
+            labels=labels, num_imgs=num_imgs, img_size=self.diffuser.model.image_size,
+            class_guidance=class_guidance, seed=seed, n_iter=n_iter, exponent=1, scale_factor=8, sharp_f=0,
+            bright_f=0)
+        return to_pil(make_image_grid((out + 1) / 2, nrow=nrow, padding=4).float().clip(0, 1))
