@@ -21,14 +21,46 @@ constexpr int kWave = 64;
 constexpr int kHeadDim = 64;
 constexpr float kLnEps = 1e-5f;
 
+// Full-wave (64-lane) all-reduce sum without LDS traffic: four DPP adds inside each 16-lane row
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then the gfx950 half-exchange instructions
+// v_permlane16_swap / v_permlane32_swap for the two cross-row steps.  Every lane ends with the total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int s = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(s);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    v = dpp_add<0x140>(v);     // row_mirror
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp, one v_exp, six FMAs.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
+    const float r = fmaf(-p, e, 1.0f);
+    return copysignf(r, x);
+}
+
+// exact-erf GELU (nn.GELU default): 0.5 x (1 + erf(x / sqrt 2)).  `precise` uses the libm-grade erff
+// (conditioning path); the fast form is for outputs that are rounded to bf16 anyway (rel 2^-9).
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 
 // ---- launch descriptors ------------------------------------------------------------------------

@@ -12,6 +12,9 @@
 // which makes every ds_read_b128 lane group touch 16 distinct 16-B slots of the 256-B bank row.
 // Two LDS stages; one barrier per K-step; the DMA of step t+1 is issued before the MFMAs of step t.
 #include "tld_common.h"
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 namespace tld {
 
@@ -164,9 +167,316 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     }
 }
 
+
+// =================================================================================================
+// 256-row tile kernel: BM = 256, BN in {256, 128}, BK = 64, 8 waves, two LDS stages.
+//
+// Why a bigger tile: with K = 768 a forward's GEMMs are short-K / long-M.  The 128x128 kernel above
+// prefetches one K-step = ~600 MFMA cycles per SIMD ahead, less than the DMA's issue->landed latency
+// under load, so every barrier waits on memory.  A 256x256 tile holds 4x the MFMA work per K-step
+// (32 MFMAs per wave, two waves per SIMD = ~2000 cycles), so the same one-step-ahead DMA has landed by
+// the time it is needed, and L2->LDS traffic per flop halves (128 flop/B).  Staging keeps FULL 128-B
+// lines per row (BK = 64): a BK = 32 ring with 64-B row segments measured no faster than the small
+// kernel -- half-line DMA pieces cost the vector memory path a full line each.
+// LDS tile image as in the 128x128 kernel: 128-B rows, chunk ^= (row >> 1) & 7, source-side swizzle.
+// Waves: BN=256 -> 2(M) x 4(N), wave tile 128 x 64 (4 x 2 MFMA tiles); BN=128 -> 4 x 2, 64 x 64.
+template <int BN>
+struct G256 {
+    static constexpr int BM = 256, BK = 64, STAGES = 2;
+    static constexpr int WN = BN / 64, WMc = 8 / WN;            // waves along N / M
+    static constexpr int WROWS = BM / WMc;                      // rows per wave: 128 or 64
+    static constexpr int TM = WROWS / 32, TN = 2;               // 32x32 MFMA tiles per wave
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
+    static constexpr int A_PIECES = BM / 8 / 8, B_PIECES = BN / 8 / 8;     // 1-KiB DMA pieces per wave per tile
+};
+
+template <int PIECES>
+__device__ __forceinline__ void stage64(const bf16* __restrict__ g, int ld, int row0, int row_max, int k0,
+                                        char* lds_tile, int wid, int lane) {
+#pragma unroll
+    for (int it = 0; it < PIECES; ++it) {
+        const int piece = wid * PIECES + it;
+        const int r = piece * 8 + (lane >> 3);
+        const int cphys = lane & 7;
+        const int clog = cphys ^ ((r >> 1) & 7);
+        int gr = row0 + r;
+        gr = gr < row_max ? gr : row_max - 1;
+        const bf16* src = g + (size_t)gr * ld + k0 + clog * 8;
+        char* dst = lds_tile + piece * 1024;                    // wave-uniform; lane i lands at +16*i
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N < 0, "unsupported vmcnt");
+}
+
+// Epilogue design (the first version stored 2 B per lane straight from the accumulators and was
+// store-ISSUE bound: ~2 B/cycle/CU, more time than the whole K loop).  Now every output leaves through
+// a per-wave LDS transpose so that global stores are 16 B per lane on whole 128/256-B row segments:
+//   * row-major outputs (q|k, MLP-up, residual add) use SWAPPED MFMA operands, D^T = W_tile . A_tile^T,
+//     which makes a lane hold 4 consecutive COLUMNS of one row (one 8/16-B LDS write per register group);
+//   * the V^T output uses the natural order (a lane holds 4 consecutive TOKENS of one feature).
+// Each wave owns LDS_BYTES/8 of the (now idle) staging memory; LDS operations of one wave complete in
+// order, so the write->read->write sequence needs no barrier beyond the one that ends the K loop.
+template <int BN, int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
+    using G = G256<BN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid / G::WN, wn = wid % G::WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int ntn = (p.N + BN - 1) / BN;
+    const int ntm = (p.M + G::BM - 1) / G::BM;
+    const int tile = xcd_remap(blockIdx.x, ntm * ntn);
+    const int m0 = (tile / ntn) * G::BM;
+    const int n0 = (tile % ntn) * BN;
+
+    // operand order: swapped => lane owns 4 consecutive columns of a row; natural => 4 consecutive rows of a column
+    bool swapped = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID);
+    if constexpr (EPI == EPI_QKV) swapped = n0 < 2 * p.d;
+
+    f32x16 acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / G::BK;
+    auto issue = [&](int t) {
+        char* st = smem + (t & 1) * G::STAGE_BYTES;
+        stage64<G::A_PIECES>(p.A, p.lda, m0, p.M, t * G::BK, st, wid, lane);
+        stage64<G::B_PIECES>(p.W, p.ldw, n0, p.N, t * G::BK, st + G::A_BYTES, wid, lane);
+    };
+    auto load_frags = [&](const char* st, int ks, bf16x8 (&a)[G::TM], bf16x8 (&b)[G::TN]) {
+        const int kc = ks * 2 + hi;
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i) a[i] = read_frag(st, wm * G::WROWS + i * 32 + l31, kc);
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) b[j] = read_frag(st + G::A_BYTES, wn * 64 + j * 32 + l31, kc);
+    };
+
+    issue(0);
+    bf16x8 a0[G::TM], b0[G::TN], a1[G::TM], b1[G::TN];
+    auto kloop = [&](auto swp) {
+        constexpr bool SW = decltype(swp)::value;
+        auto mma = [&](const bf16x8 (&a)[G::TM], const bf16x8 (&b)[G::TN]) {
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < G::TN; ++j) {
+                    if constexpr (SW) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+        };
+        for (int t = 0; t < nk; ++t) {
+            wait_vmcnt<0>();                       // this wave's pieces of tile t have landed
+            __builtin_amdgcn_s_barrier();          // ... everybody's; and stage (t+1)&1 is no longer read
+            const char* st = smem + (t & 1) * G::STAGE_BYTES;
+            load_frags(st, 0, a0, b0);
+            if (t + 1 < nk) issue(t + 1);          // DMA address math overlaps the first fragment reads
+            load_frags(st, 1, a1, b1);
+            mma(a0, b0);
+            load_frags(st, 2, a0, b0);
+            mma(a1, b1);
+            load_frags(st, 3, a1, b1);
+            mma(a0, b0);
+            mma(a1, b1);
+        }
+    };
+    if constexpr (EPI == EPI_QKV) {
+        if (swapped) kloop(std::true_type{}); else kloop(std::false_type{});
+    } else if constexpr (EPI == EPI_F32) {
+        kloop(std::false_type{});
+    } else {
+        kloop(std::true_type{});
+    }
+
+    const int row0 = m0 + wm * G::WROWS;          // first global row of this wave's sub-tile
+    const int col0 = n0 + wn * 64;                // first global column
+    const bool wide_ok = (p.N % 8 == 0) && (col0 + 64 <= p.N);
+
+    if constexpr (EPI == EPI_F32) {
+        // debug / test path: direct stores, natural layout (col = lane & 31, row = (r&3) + 8(r>>2) + 4 hi)
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j) {
+                const int col = col0 + j * 32 + l31;
+                if (col >= p.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) p.c_f32[(size_t)row * p.ldc + col] = acc[i][j][r];
+                }
+            }
+        return;
+    } else {
+        __builtin_amdgcn_s_barrier();              // all waves are done reading the staging buffers
+        char* ws = smem + wid * (G::LDS_BYTES / 8);
+
+        if constexpr (EPI == EPI_BIAS_RESID) {
+            // x[row, col] += acc + bias[col]; one 32-row MFMA tile-row per pass through LDS (fp32, pitch 272 B)
+            constexpr int P = 64 * 4 + 16;
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int cl = j * 32 + 8 * rq + 4 * hi;
+                        const int cg = col0 + cl < p.N ? col0 + cl : 0;
+                        const float4 bv = *reinterpret_cast<const float4*>(p.bias + cg);
+                        float4 v;
+                        v.x = acc[i][j][rq * 4 + 0] + bv.x; v.y = acc[i][j][rq * 4 + 1] + bv.y;
+                        v.z = acc[i][j][rq * 4 + 2] + bv.z; v.w = acc[i][j][rq * 4 + 3] + bv.w;
+                        *reinterpret_cast<float4*>(ws + l31 * P + cl * 4) = v;
+                    }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int rl = idx >> 4, ch = idx & 15;
+                    const float4 v = *reinterpret_cast<const float4*>(ws + rl * P + ch * 16);
+                    const int row = row0 + i * 32 + rl, col = col0 + ch * 4;
+                    if (row < p.M && col < p.N) {
+                        float4* px = reinterpret_cast<float4*>(p.resid + (size_t)row * p.ldr + col);
+                        float4 o = *px;
+                        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                        *px = o;
+                    }
+                }
+            }
+        } else {
+            // bf16 outputs
+            const bool to_vt = (EPI == EPI_QKV) && !swapped;
+            if (!to_vt) {
+                // row-major [rows][64] bf16, 128-B pitch (exactly fills the wave's LDS share), 16-B chunk index
+                // XOR-swizzled with (row & 7); swapped layout: row = i*32 + l31, cols 4-consecutive
+                constexpr int P = 64 * 2;
+#pragma unroll
+                for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const int cl = j * 32 + 8 * rq + 4 * hi;
+                            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if constexpr (EPI == EPI_BIAS_BF16) {
+                                const int cg = col0 + cl < p.N ? col0 + cl : 0;
+                                bv = *reinterpret_cast<const float4*>(p.bias + cg);
+                            }
+                            bf16x4 pk;
+                            pk[0] = (bf16)(acc[i][j][rq * 4 + 0] + bv.x);
+                            pk[1] = (bf16)(acc[i][j][rq * 4 + 1] + bv.y);
+                            pk[2] = (bf16)(acc[i][j][rq * 4 + 2] + bv.z);
+                            pk[3] = (bf16)(acc[i][j][rq * 4 + 3] + bv.w);
+                            const int rl = i * 32 + l31;
+                            *reinterpret_cast<bf16x4*>(ws + rl * P + ((((cl >> 3) ^ (rl & 7)) << 4) | ((cl & 7) << 1))) = pk;
+                        }
+#pragma unroll
+                for (int it = 0; it < G::WROWS / 8; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int rl = idx >> 3, ch = idx & 7;
+                    const uint4 v = *reinterpret_cast<const uint4*>(ws + rl * P + ((ch ^ (rl & 7)) << 4));
+                    const int row = row0 + rl, col = col0 + ch * 8;
+                    if (row < p.M && col < p.N)
+                        *reinterpret_cast<uint4*>(p.out_bf16 + (size_t)row * p.ldo + col) = v;
+                }
+            } else {
+                // V^T: [64 features][64 tokens] bf16 per pass (pitch 144 B); natural layout:
+                // feature = j*32 + l31, tokens 4-consecutive: i*32 + 8 rq + 4 hi
+                constexpr int P = 64 * 2 + 16;
+                const int cbase = col0 - 2 * p.d;              // feature index (h*64 + c) of local column 0
+#pragma unroll
+                for (int half = 0; half < G::TM / 2; ++half) {
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+                            for (int rq = 0; rq < 4; ++rq) {
+                                const int i = half * 2 + ii;
+                                bf16x4 pk;
+                                pk[0] = (bf16)acc[i][j][rq * 4 + 0]; pk[1] = (bf16)acc[i][j][rq * 4 + 1];
+                                pk[2] = (bf16)acc[i][j][rq * 4 + 2]; pk[3] = (bf16)acc[i][j][rq * 4 + 3];
+                                *reinterpret_cast<bf16x4*>(ws + (j * 32 + l31) * P + (ii * 32 + 8 * rq + 4 * hi) * 2) = pk;
+                            }
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int idx = it * 64 + lane;
+                        const int f = idx >> 3, ch = idx & 7;                   // feature row, 8-token chunk
+                        const uint4 v = *reinterpret_cast<const uint4*>(ws + f * P + ch * 16);
+                        const int row = row0 + half * 64 + ch * 8;              // global token row of this chunk
+                        if (row < p.M && col0 + f < p.N) {
+                            const int b = row / p.ntok, tk = row - b * p.ntok;
+                            *reinterpret_cast<uint4*>(p.vt + ((size_t)b * p.d + cbase + f) * p.ntok + tk) = v;
+                        }
+                    }
+                }
+            }
+        }
+        (void)wide_ok;
+    }
+}
+
+template <int BN>
+void launch256(const GemmParams& p, int epilogue, hipStream_t s) {
+    using G = G256<BN>;
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + G::BM - 1) / G::BM;
+    dim3 grid(ntm * ntn), block(512);
+#define TLD_L256(E)                                                                                   \
+    do {                                                                                              \
+        static bool once = false;                                                                     \
+        if (!once) {                                                                                  \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256_kernel<BN, E>),                 \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);            \
+            once = true;                                                                              \
+        }                                                                                             \
+        hipLaunchKernelGGL((gemm256_kernel<BN, E>), grid, block, G::LDS_BYTES, s, p);                 \
+    } while (0)
+    switch (epilogue) {
+        case EPI_F32: TLD_L256(EPI_F32); break;
+        case EPI_QKV: TLD_L256(EPI_QKV); break;
+        case EPI_BIAS_BF16: TLD_L256(EPI_BIAS_BF16); break;
+        case EPI_BIAS_RESID: TLD_L256(EPI_BIAS_RESID); break;
+        default: break;
+    }
+#undef TLD_L256
+}
+
 }  // namespace
 
+static int gemm_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("TLD_GEMM");          // "128": 2-stage 128x128 kernel; default: 256-row ring kernel
+        v = (e && !strcmp(e, "128")) ? 128 : 256;
+    }
+    return v;
+}
+
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s) {
+    if (gemm_variant() == 256 && p.K % 64 == 0) {
+        // BN = 256 unless that leaves the last round of workgroups mostly empty on 256 CUs
+        const long ntm = (p.M + 255) / 256;
+        const long blocks256 = ntm * ((p.N + 255) / 256);
+        const bool narrow = (p.N % 256 != 0) || (blocks256 % 256 != 0 && blocks256 < 3 * 256);
+        static const char* force = getenv("TLD_GEMM_BN");
+        if (force ? !strcmp(force, "128") : narrow) launch256<128>(p, epilogue, s);
+        else launch256<256>(p, epilogue, s);
+        return;
+    }
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     dim3 grid(ntm * ntn), block(256);
     switch (epilogue) {

@@ -15,80 +15,77 @@ namespace tld {
 
 namespace {
 
-constexpr int MAXJ = 8;   // d <= 1024
 
 // ------------------------------------------------------------------------------------------------
+template <int NJ>
 __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // token row in [0, B*N)
+    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // token row
     if (row >= p.batch * p.ntok) return;
     const int b = row / p.ntok, t = row - b * p.ntok;
     const int ti = t / p.grid, tj = t - ti * p.grid;
-    const int cpp = p.C * p.p * p.p;
+    const int pp = p.p * p.p, cpp = p.C * pp;
 
-    // patchify conv: lane o < pd computes feature o of this patch
-    float pv = 0.f;
-    if (lane < p.pd) {
-        pv = p.conv_b[lane];
-        for (int c = 0; c < p.C; ++c)
-            for (int u = 0; u < p.p; ++u)
-                for (int v = 0; v < p.p; ++v) {
-                    const float xv = p.x[(((size_t)(b % p.src_batch) * p.C + c) * p.S + (ti * p.p + u)) * p.S + (tj * p.p + v)];
-                    pv += p.conv_w[lane * cpp + (c * p.p + u) * p.p + v] * xv;
-                }
+    // the patch's C*p*p input values, one per lane (lane = (c, u, v))
+    float xin = 0.f;
+    if (lane < cpp) {
+        const int c = lane / pp, uv = lane - c * pp, u = uv / p.p, v = uv - u * p.p;
+        xin = p.x[(((size_t)(b % p.src_batch) * p.C + c) * p.S + (ti * p.p + u)) * p.S + (tj * p.p + v)];
     }
+    // patchify conv: lane o < pd computes feature o
+    float pv = lane < p.pd ? p.conv_b[lane] : 0.f;
+    const float* cw = p.conv_w + (lane < p.pd ? lane : 0) * cpp;
+    for (int i = 0; i < cpp; ++i) {
+        const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xin), i));
+        pv = fmaf(cw[i], xv, pv);
+    }
+    if (lane >= p.pd) pv = 0.f;
     // LN over pd
     const float inv_pd = 1.0f / (float)p.pd;
-    const float mean1 = wave_sum(lane < p.pd ? pv : 0.f) * inv_pd;
+    const float mean1 = wave_sum(pv) * inv_pd;
     const float dv = lane < p.pd ? pv - mean1 : 0.f;
-    const float var1 = wave_sum(dv * dv) * inv_pd;
-    const float rstd1 = 1.0f / sqrtf(var1 + kLnEps);
+    const float rstd1 = 1.0f / sqrtf(wave_sum(dv * dv) * inv_pd + kLnEps);
     float pn = 0.f;
     if (lane < p.pd) pn = dv * rstd1 * p.ln1_w[lane] + p.ln1_b[lane];
 
-    // Linear pd -> d: lane owns features {2l,2l+1} + 128 j
-    const int nj = p.d / 128;
-    float2 e[MAXJ];
+    // Linear pd -> d: lane owns features {2l, 2l+1} + 128 j
+    float2 e[NJ];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        if (j < nj) e[j] = *reinterpret_cast<const float2*>(p.lin_b + j * 128 + 2 * lane);
-        else e[j] = make_float2(0.f, 0.f);
-    }
+    for (int j = 0; j < NJ; ++j) e[j] = *reinterpret_cast<const float2*>(p.lin_b + j * 128 + 2 * lane);
+#pragma unroll 4
     for (int o = 0; o < p.pd; ++o) {
-        const float a = __shfl(pn, o, 64);
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pn), o));
         const float* wrow = p.lin_wt + (size_t)o * p.d + 2 * lane;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (j < nj) {
-                const float2 w = *reinterpret_cast<const float2*>(wrow + j * 128);
-                e[j].x += a * w.x; e[j].y += a * w.y;
-            }
+        for (int j = 0; j < NJ; ++j) {
+            const float2 w = *reinterpret_cast<const float2*>(wrow + j * 128);
+            e[j].x = fmaf(a, w.x, e[j].x); e[j].y = fmaf(a, w.y, e[j].y);
+        }
     }
     // LN over d
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) if (j < nj) s += e[j].x + e[j].y;
+    for (int j = 0; j < NJ; ++j) s += e[j].x + e[j].y;
     const float mean2 = wave_sum(s) / (float)p.d;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
-        if (j < nj) { e[j].x -= mean2; e[j].y -= mean2; q += e[j].x * e[j].x + e[j].y * e[j].y; }
+    for (int j = 0; j < NJ; ++j) { e[j].x -= mean2; e[j].y -= mean2; q += e[j].x * e[j].x + e[j].y * e[j].y; }
     const float rstd2 = 1.0f / sqrtf(wave_sum(q) / (float)p.d + kLnEps);
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
-        if (j < nj) {
-            const int n = j * 128 + 2 * lane;
-            const float2 g = *reinterpret_cast<const float2*>(p.ln2_w + n);
-            const float2 bb = *reinterpret_cast<const float2*>(p.ln2_b + n);
-            const float2 pe = *reinterpret_cast<const float2*>(p.pos + (size_t)t * p.d + n);
-            float2 o;
-            o.x = e[j].x * rstd2 * g.x + bb.x + pe.x;
-            o.y = e[j].y * rstd2 * g.y + bb.y + pe.y;
-            *reinterpret_cast<float2*>(p.tok + (size_t)row * p.d + n) = o;
-        }
+    for (int j = 0; j < NJ; ++j) {
+        const int n = j * 128 + 2 * lane;
+        const float2 g = *reinterpret_cast<const float2*>(p.ln2_w + n);
+        const float2 bb = *reinterpret_cast<const float2*>(p.ln2_b + n);
+        const float2 pe = *reinterpret_cast<const float2*>(p.pos + (size_t)t * p.d + n);
+        float2 o;
+        o.x = e[j].x * rstd2 * g.x + bb.x + pe.x;
+        o.y = e[j].y * rstd2 * g.y + bb.y + pe.y;
+        *reinterpret_cast<float2*>(p.tok + (size_t)row * p.d + n) = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
+template <int NJ>
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const resid_t* __restrict__ x,
                                                              const float* __restrict__ g,
                                                              const float* __restrict__ b,
@@ -96,32 +93,28 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const resid_t* __re
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const int nj = d / 128;
-    float2 v[MAXJ];
+    float2 v[NJ];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
-        if (j < nj) {
-            v[j] = *reinterpret_cast<const float2*>(x + (size_t)row * d + j * 128 + 2 * lane);
-            s += v[j].x + v[j].y;
-        }
+    for (int j = 0; j < NJ; ++j) {
+        v[j] = *reinterpret_cast<const float2*>(x + (size_t)row * d + j * 128 + 2 * lane);
+        s += v[j].x + v[j].y;
+    }
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
-        if (j < nj) { v[j].x -= mean; v[j].y -= mean; q += v[j].x * v[j].x + v[j].y * v[j].y; }
+    for (int j = 0; j < NJ; ++j) { v[j].x -= mean; v[j].y -= mean; q += v[j].x * v[j].x + v[j].y * v[j].y; }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j)
-        if (j < nj) {
-            const int n = j * 128 + 2 * lane;
-            const float2 gg = *reinterpret_cast<const float2*>(g + n);
-            const float2 bb = *reinterpret_cast<const float2*>(b + n);
-            bf16x2 o;
-            o[0] = (bf16)(v[j].x * rstd * gg.x + bb.x);
-            o[1] = (bf16)(v[j].y * rstd * gg.y + bb.y);
-            *reinterpret_cast<bf16x2*>(out + (size_t)row * d + n) = o;
-        }
+    for (int j = 0; j < NJ; ++j) {
+        const int n = j * 128 + 2 * lane;
+        const float2 gg = *reinterpret_cast<const float2*>(g + n);
+        const float2 bb = *reinterpret_cast<const float2*>(b + n);
+        bf16x2 o;
+        o[0] = (bf16)(v[j].x * rstd * gg.x + bb.x);
+        o[1] = (bf16)(v[j].y * rstd * gg.y + bb.y);
+        *reinterpret_cast<bf16x2*>(out + (size_t)row * d + n) = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -131,9 +124,10 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const resid_t* __re
 // (token row, head), prepared once on the conditioning path (wq table, LN2 gamma folded in, LN2 beta
 // contribution in bwq).  The sub-block therefore needs no GEMM: per row it is 12 dot products of
 // the centred row against LDS-resident vectors, a sigmoid per head, and a blend of the two value rows.
+template <int NJ>
 __global__ __launch_bounds__(256) void cross_row_kernel(CrossRowParams p, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int d = p.d, H = p.heads;
+    constexpr int d = NJ * 128, H = NJ * 2;
     float* wd = reinterpret_cast<float*>(smem);          // [H][d]  wq_label - wq_noise (gamma folded)
     float* vn = wd + H * d;                              // [d]     value row of the noise token
     float* vdiff = vn + d;                               // [d]     v_label - v_noise
@@ -144,8 +138,15 @@ __global__ __launch_bounds__(256) void cross_row_kernel(CrossRowParams p, int ro
     const int r0 = (blockIdx.x - b * blocks_per_sample) * rows_per_block;
     const int tn = p.noise_row[b], tl = p.label_row[b];
 
-    for (int i = threadIdx.x; i < H * d; i += 256)
-        wd[i] = p.wq[(size_t)tl * H * d + i] - p.wq[(size_t)tn * H * d + i];
+    {
+        const float4* wl = reinterpret_cast<const float4*>(p.wq + (size_t)tl * H * d);
+        const float4* wn = reinterpret_cast<const float4*>(p.wq + (size_t)tn * H * d);
+        float4* dst = reinterpret_cast<float4*>(wd);
+        for (int i = threadIdx.x; i < H * d / 4; i += 256) {
+            const float4 a = wl[i], c = wn[i];
+            dst[i] = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
+        }
+    }
     for (int i = threadIdx.x; i < d; i += 256) {
         const float a = p.v[(size_t)tn * p.v_ld + i];
         vn[i] = a;
@@ -155,119 +156,114 @@ __global__ __launch_bounds__(256) void cross_row_kernel(CrossRowParams p, int ro
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int nj = d / 128;
+    const bool upper = lane >= 32;
     const int rows_per_wave = rows_per_block / 4;
     for (int rr = 0; rr < rows_per_wave; ++rr) {
         const size_t row = (size_t)b * p.ntok + r0 + wid * rows_per_wave + rr;
-        float2 v[MAXJ];
+        float2 v[NJ];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (j < nj) {
-                const int n = j * 128 + 2 * lane;
-                const float2 xv = *reinterpret_cast<const float2*>(p.x + row * d + n);
-                const bf16x2 av = *reinterpret_cast<const bf16x2*>(p.att + row * d + n);
-                v[j].x = xv.x + (float)av[0];               // x = SA(LN1 x) + x
-                v[j].y = xv.y + (float)av[1];
-                s += v[j].x + v[j].y;
-                if (p.sa_out) *reinterpret_cast<float2*>(p.sa_out + row * d + n) = v[j];
-            }
+        for (int j = 0; j < NJ; ++j) {
+            const int n = j * 128 + 2 * lane;
+            const float2 xv = *reinterpret_cast<const float2*>(p.x + row * d + n);
+            const bf16x2 av = *reinterpret_cast<const bf16x2*>(p.att + row * d + n);
+            v[j].x = xv.x + (float)av[0];                   // x = SA(LN1 x) + x
+            v[j].y = xv.y + (float)av[1];
+            s += v[j].x + v[j].y;
+            if (p.sa_out) *reinterpret_cast<float2*>(p.sa_out + row * d + n) = v[j];
+        }
         const float mean = wave_sum(s) / (float)d;
+        float2 c[NJ];
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (j < nj) {
-                const float cx = v[j].x - mean, cy = v[j].y - mean;
-                q += cx * cx + cy * cy;
-            }
+        for (int j = 0; j < NJ; ++j) {
+            c[j].x = v[j].x - mean; c[j].y = v[j].y - mean;
+            q += c[j].x * c[j].x + c[j].y * c[j].y;
+        }
         const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
 
-        // per-head logit difference -> sigmoid weight of the label token
+        // per-head logit difference -> sigmoid weight of the label token.
         // lane's features of group j belong to head 2j + (lane >> 5)
-        float plab[MAXJ];
+        float plab[NJ];
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) plab[j] = 0.f;
-        for (int h = 0; h < H; ++h) {
-            float part = 0.f;
-            const float* wrow = wd + h * d + 2 * lane;
+        for (int hh = 0; hh < NJ; ++hh) {
+            float part0 = 0.f, part1 = 0.f;
+            const float* w0 = wd + (2 * hh) * d + 2 * lane;
+            const float* w1 = w0 + d;
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j)
-                if (j < nj) {
-                    const float2 w = *reinterpret_cast<const float2*>(wrow + j * 128);
-                    part += (v[j].x - mean) * w.x + (v[j].y - mean) * w.y;
-                }
-            const float delta = wave_sum(part) * rstd + bw[h];
-            const float sg = 1.0f / (1.0f + __expf(-delta));
-            const int myj = h >> 1;
-            const bool mine = ((h & 1) == (lane >> 5));
-#pragma unroll
-            for (int j = 0; j < MAXJ; ++j)
-                if (j == myj && mine) plab[j] = sg;
+            for (int j = 0; j < NJ; ++j) {
+                const float2 a = *reinterpret_cast<const float2*>(w0 + j * 128);
+                const float2 e = *reinterpret_cast<const float2*>(w1 + j * 128);
+                part0 = fmaf(c[j].x, a.x, fmaf(c[j].y, a.y, part0));
+                part1 = fmaf(c[j].x, e.x, fmaf(c[j].y, e.y, part1));
+            }
+            const float d0 = wave_sum(part0) * rstd + bw[2 * hh];
+            const float d1 = wave_sum(part1) * rstd + bw[2 * hh + 1];
+            const float dl = upper ? d1 : d0;
+            plab[hh] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-dl * 1.44269504088896340736f));
         }
         // x += p_noise v_n + p_label v_l ; then LN3
         float s3 = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (j < nj) {
-                const int n = j * 128 + 2 * lane;
-                const float2 a = *reinterpret_cast<const float2*>(vn + n);
-                const float2 dd = *reinterpret_cast<const float2*>(vdiff + n);
-                v[j].x += a.x + plab[j] * dd.x;
-                v[j].y += a.y + plab[j] * dd.y;
-                *reinterpret_cast<float2*>(p.x + row * d + n) = v[j];
-                s3 += v[j].x + v[j].y;
-            }
+        for (int j = 0; j < NJ; ++j) {
+            const int n = j * 128 + 2 * lane;
+            const float2 a = *reinterpret_cast<const float2*>(vn + n);
+            const float2 dd = *reinterpret_cast<const float2*>(vdiff + n);
+            v[j].x += fmaf(plab[j], dd.x, a.x);
+            v[j].y += fmaf(plab[j], dd.y, a.y);
+            *reinterpret_cast<float2*>(p.x + row * d + n) = v[j];
+            s3 += v[j].x + v[j].y;
+        }
         const float mean3 = wave_sum(s3) / (float)d;
         float q3 = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (j < nj) {
-                v[j].x -= mean3; v[j].y -= mean3;
-                q3 += v[j].x * v[j].x + v[j].y * v[j].y;
-            }
+        for (int j = 0; j < NJ; ++j) {
+            v[j].x -= mean3; v[j].y -= mean3;
+            q3 += v[j].x * v[j].x + v[j].y * v[j].y;
+        }
         const float rstd3 = 1.0f / sqrtf(wave_sum(q3) / (float)d + kLnEps);
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (j < nj) {
-                const int n = j * 128 + 2 * lane;
-                const float2 gg = *reinterpret_cast<const float2*>(p.ln3_w + n);
-                const float2 bb = *reinterpret_cast<const float2*>(p.ln3_b + n);
-                bf16x2 o;
-                o[0] = (bf16)(v[j].x * rstd3 * gg.x + bb.x);
-                o[1] = (bf16)(v[j].y * rstd3 * gg.y + bb.y);
-                *reinterpret_cast<bf16x2*>(p.xn3 + row * d + n) = o;
-            }
+        for (int j = 0; j < NJ; ++j) {
+            const int n = j * 128 + 2 * lane;
+            const float2 gg = *reinterpret_cast<const float2*>(p.ln3_w + n);
+            const float2 bb = *reinterpret_cast<const float2*>(p.ln3_b + n);
+            bf16x2 o;
+            o[0] = (bf16)(v[j].x * rstd3 * gg.x + bb.x);
+            o[1] = (bf16)(v[j].y * rstd3 * gg.y + bb.y);
+            *reinterpret_cast<bf16x2*>(p.xn3 + row * d + n) = o;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // out_proj + unpatchify.  16 tokens per wave, weights [pd][d] fp32 resident in LDS.
+template <int NJ>
 __global__ __launch_bounds__(256) void tail_kernel(TailParams p, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int d = NJ * 128;
     float* w = reinterpret_cast<float*>(smem);           // [pd][d]
-    for (int i = threadIdx.x; i < p.pd * p.d; i += 256) w[i] = p.w[i];
+    for (int i = threadIdx.x; i < p.pd * d / 4; i += 256)
+        reinterpret_cast<float4*>(w)[i] = reinterpret_cast<const float4*>(p.w)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int nj = p.d / 128;
     const int rows_per_wave = rows_per_block / 4;
     const int total = p.batch * p.ntok;
     for (int rr = 0; rr < rows_per_wave; ++rr) {
         const int row = blockIdx.x * rows_per_block + wid * rows_per_wave + rr;
         if (row >= total) return;
-        float2 v[MAXJ];
+        float2 v[NJ];
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j)
-            if (j < nj) v[j] = *reinterpret_cast<const float2*>(p.tok + (size_t)row * p.d + j * 128 + 2 * lane);
+        for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const float2*>(p.tok + (size_t)row * d + j * 128 + 2 * lane);
         float mine = 0.f;
+#pragma unroll 4
         for (int o = 0; o < p.pd; ++o) {
             float part = 0.f;
-            const float* wrow = w + o * p.d + 2 * lane;
+            const float* wrow = w + o * d + 2 * lane;
 #pragma unroll
-            for (int j = 0; j < MAXJ; ++j)
-                if (j < nj) {
-                    const float2 ww = *reinterpret_cast<const float2*>(wrow + j * 128);
-                    part += v[j].x * ww.x + v[j].y * ww.y;
-                }
+            for (int j = 0; j < NJ; ++j) {
+                const float2 ww = *reinterpret_cast<const float2*>(wrow + j * 128);
+                part = fmaf(v[j].x, ww.x, fmaf(v[j].y, ww.y, part));
+            }
             const float tot = wave_sum(part);
             if (lane == o) mine = tot + p.b[o];
         }
@@ -360,7 +356,7 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const bf16* __restrict
             for (int du = 0; du < 3; ++du)
 #pragma unroll
                 for (int dv = 0; dv < 3; ++dv) acc += w[du * 3 + dv][e] * (float)win[dv][du][e];
-            o[e] = (bf16)gelu_erf(acc);
+            o[e] = (bf16)gelu_erf_fast(acc);
         }
         *reinterpret_cast<bf16x8*>(out + (((size_t)b * g + i) * g + j) * C + c0) = o;
 #pragma unroll
@@ -370,28 +366,41 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const bf16* __restrict
 
 }  // namespace
 
+#define TLD_DISPATCH_NJ(nj, CALL)                                                                  \
+    switch (nj) {                                                                                    \
+        case 1: { constexpr int NJ = 1; CALL; } break;                                              \
+        case 2: { constexpr int NJ = 2; CALL; } break;                                              \
+        case 3: { constexpr int NJ = 3; CALL; } break;                                              \
+        case 4: { constexpr int NJ = 4; CALL; } break;                                              \
+        case 5: { constexpr int NJ = 5; CALL; } break;                                              \
+        case 6: { constexpr int NJ = 6; CALL; } break;                                              \
+        case 7: { constexpr int NJ = 7; CALL; } break;                                              \
+        case 8: { constexpr int NJ = 8; CALL; } break;                                              \
+        default: break;                                                                              \
+    }
+
 void launch_embed(const EmbedParams& p, hipStream_t s) {
     const int rows = p.batch * p.ntok;
-    hipLaunchKernelGGL(embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, p);
+    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(embed_kernel<NJ>, dim3((rows + 3) / 4), dim3(256), 0, s, p));
 }
 
 void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf16* out, int M, int d,
                            hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_bf16_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d);
+    TLD_DISPATCH_NJ(d / 128, hipLaunchKernelGGL(layernorm_bf16_kernel<NJ>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d));
 }
 
 void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
     const int rpb = (p.ntok % 64 == 0) ? 64 : 32;
     const int lds = (p.heads * p.d + 2 * p.d + p.heads) * (int)sizeof(float);
     dim3 grid(p.batch * (p.ntok / rpb));
-    hipLaunchKernelGGL(cross_row_kernel, grid, dim3(256), lds, s, p, rpb);
+    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(cross_row_kernel<NJ>, grid, dim3(256), lds, s, p, rpb));
 }
 
 void launch_tail(const TailParams& p, hipStream_t s) {
     const int rpb = 64;
     const int rows = p.batch * p.ntok;
     const int lds = p.pd * p.d * (int)sizeof(float);
-    hipLaunchKernelGGL(tail_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), lds, s, p, rpb);
+    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(tail_kernel<NJ>, dim3((rows + rpb - 1) / rpb), dim3(256), lds, s, p, rpb));
 }
 
 void launch_update(const UpdateParams& p, hipStream_t s) {
