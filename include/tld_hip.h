@@ -101,6 +101,12 @@ TLD_API int tld_engine_read_stage(tld_engine* e, const char* name, float* host_o
 TLD_API int tld_debug_gemm_bf16(const void* a_bf16, const void* w_bf16, float* c_f32, int32_t M, int32_t N,
                         int32_t K, void* hip_stream);
 
+/* Test/bench hook: time the engine's GEMM on self-allocated, pseudo-randomly filled device buffers.
+ * epilogue: 0 fp32 out, 1 QKV (q|k row-major + V^T; N = 3*d, ntok tokens per sample), 2 bias+bf16,
+ * 3 bias + fp32 residual add.  Returns the average kernel time over `iters` launches (HIP events). */
+TLD_API int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t ntok, int32_t iters,
+                                 double* avg_ms);
+
 /* Live per-kernel-class timing with HIP events recorded on the launch stream around every launch
  * of the selected classes (bit k of class_mask).  Classes: 0 gemm_qkv, 1 gemm_up, 2 gemm_down,
  * 3 attention, 4 cross_row, 5 dwconv_gelu, 6 layernorm, 7 embed, 8 tail, 9 update, 10 conditioning.

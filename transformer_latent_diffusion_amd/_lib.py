@@ -20,7 +20,7 @@ KERNEL_CLASSES = ("gemm_qkv", "gemm_up", "gemm_down", "attention", "cross_row", 
 # every symbol include/tld_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "tld_engine_create", "tld_engine_load_tensor", "tld_engine_finalize_weights", "tld_denoiser_forward",
-    "tld_sample", "tld_engine_set_debug", "tld_engine_read_stage", "tld_debug_gemm_bf16",
+    "tld_sample", "tld_engine_set_debug", "tld_engine_read_stage", "tld_debug_gemm_bf16", "tld_debug_gemm_bench",
     "tld_engine_set_profile", "tld_engine_get_profile", "tld_engine_weight_bytes", "tld_engine_destroy",
     "tld_last_error",
 )
@@ -66,6 +66,7 @@ def lib() -> C.CDLL:
     L.tld_engine_set_debug.argtypes = [vp, i32]
     L.tld_engine_read_stage.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
     L.tld_debug_gemm_bf16.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.tld_debug_gemm_bench.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     L.tld_engine_set_profile.argtypes = [vp, C.c_uint32]
     L.tld_engine_get_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.tld_engine_weight_bytes.argtypes = [vp]

@@ -168,5 +168,6 @@ void launch_wq(const float* k, int ldk, const float* Wq, const float* gamma, con
 void launch_cast_to_f32(const void* src, int dtype, float* dst, int64_t n, hipStream_t s);
 void launch_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);
 void launch_iota(int* dst, int n, int base, hipStream_t s);
+void launch_fill_bf16(bf16* dst, int64_t n, uint32_t seed, float scale, hipStream_t s);
 
 }  // namespace tld

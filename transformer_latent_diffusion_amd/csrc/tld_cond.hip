@@ -142,6 +142,14 @@ __global__ void iota_kernel(int* __restrict__ dst, int n, int base) {
     if (i < n) dst[i] = base + i;
 }
 
+__global__ void fill_bf16_kernel(bf16* __restrict__ dst, int64_t n, uint32_t seed, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = (uint32_t)i * 2654435761u + seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    dst[i] = (bf16)(((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f) * scale);
+}
+
 template <typename T>
 __global__ void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,6 +188,10 @@ void launch_wq(const float* k, int ldk, const float* Wq, const float* gamma, con
 
 void launch_iota(int* dst, int n, int base, hipStream_t s) {
     hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, n, base);
+}
+
+void launch_fill_bf16(bf16* dst, int64_t n, uint32_t seed, float scale, hipStream_t s) {
+    hipLaunchKernelGGL(fill_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dst, n, seed, scale);
 }
 
 void launch_cast_to_f32(const void* src, int dtype, float* dst, int64_t n, hipStream_t s) {

@@ -567,6 +567,38 @@ int tld_debug_gemm_bf16(const void* a, const void* w, float* c, int32_t M, int32
     return TLD_OK;
 }
 
+int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t ntok, int32_t iters,
+                         double* avg_ms) {
+    if (!avg_ms || M <= 0 || N <= 0 || K <= 0 || K % 64 || iters <= 0) return fail(TLD_ERR_INVALID, "bad argument");
+    if (epilogue == EPI_QKV && (N % 3 || ntok <= 0 || M % ntok)) return fail(TLD_ERR_INVALID, "QKV epilogue needs N = 3d, M %% ntok == 0");
+    bf16 *A = nullptr, *W = nullptr, *out = nullptr, *vt = nullptr;
+    float *bias = nullptr, *res = nullptr;
+    HIP_TRY(hipMalloc(&A, (size_t)M * K * 2)); HIP_TRY(hipMalloc(&W, (size_t)N * K * 2));
+    HIP_TRY(hipMalloc(&out, (size_t)M * N * 2)); HIP_TRY(hipMalloc(&vt, (size_t)M * N * 2));
+    HIP_TRY(hipMalloc(&bias, (size_t)N * 4)); HIP_TRY(hipMalloc(&res, (size_t)M * N * 4));
+    launch_fill_bf16(A, (int64_t)M * K, 1u, 1.0f, nullptr);
+    launch_fill_bf16(W, (int64_t)N * K, 2u, 0.05f, nullptr);
+    HIP_TRY(hipMemset(bias, 0, (size_t)N * 4)); HIP_TRY(hipMemset(res, 0, (size_t)M * N * 4));
+    GemmParams g{};
+    g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;
+    g.c_f32 = res; g.ldc = N; g.out_bf16 = out; g.ldo = epilogue == EPI_QKV ? 2 * (N / 3) : N; g.vt = vt;
+    g.ntok = ntok > 0 ? ntok : 1; g.d = N / 3; g.bias = bias; g.resid = res; g.ldr = N;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) launch_gemm(g, epilogue, nullptr);
+    HIP_TRY(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) launch_gemm(g, epilogue, nullptr);
+    HIP_TRY(hipEventRecord(b, nullptr));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    *avg_ms = ms / iters;
+    hipEventDestroy(a); hipEventDestroy(b);
+    hipFree(A); hipFree(W); hipFree(out); hipFree(vt); hipFree(bias); hipFree(res);
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
 int tld_engine_set_profile(tld_engine* e, uint32_t class_mask) {
     if (!e) return fail(TLD_ERR_INVALID, "null engine");
     for (int k = 0; k < KC_COUNT; ++k) {

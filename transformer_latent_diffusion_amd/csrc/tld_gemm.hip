@@ -179,13 +179,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 // lines per row (BK = 64): a BK = 32 ring with 64-B row segments measured no faster than the small
 // kernel -- half-line DMA pieces cost the vector memory path a full line each.
 // LDS tile image as in the 128x128 kernel: 128-B rows, chunk ^= (row >> 1) & 7, source-side swizzle.
-// Waves: BN=256 -> 2(M) x 4(N), wave tile 128 x 64 (4 x 2 MFMA tiles); BN=128 -> 4 x 2, 64 x 64.
+// Waves: BN=256 -> 2(M) x 4(N), wave tile 128 x 64 (4 x 2 MFMA tiles); BN=128 -> 4 x 2, 64 x 64;
+// BN=192 -> 4 x 2, 64 x 96 (residual-add epilogue only: N = 768 then fills 256 CUs in exactly 2 rounds).
 template <int BN>
 struct G256 {
     static constexpr int BM = 256, BK = 64, STAGES = 2;
-    static constexpr int WN = BN / 64, WMc = 8 / WN;            // waves along N / M
+    static constexpr int WN = (BN == 256) ? 4 : 2, WMc = 8 / WN;   // waves along N / M
     static constexpr int WROWS = BM / WMc;                      // rows per wave: 128 or 64
-    static constexpr int TM = WROWS / 32, TN = 2;               // 32x32 MFMA tiles per wave
+    static constexpr int WCOLS = BN / WN;                       // cols per wave: 64 (BN 256/128) or 96 (BN 192)
+    static constexpr int TM = WROWS / 32, TN = WCOLS / 32;      // 32x32 MFMA tiles per wave
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
@@ -237,9 +239,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 
     const int ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + G::BM - 1) / G::BM;
+    // tile order inside an XCD's contiguous run: super-rows of 8 m-panels, n-tiles outer, m-panels inner,
+    // so any 32 co-resident workgroups of an XCD (one per CU) touch ~8 A panels + ~4 W panels instead of
+    // ~3 + all n-tiles: fewer distinct K-slices competing for the 4 MiB L2 at any moment.
     const int tile = xcd_remap(blockIdx.x, ntm * ntn);
-    const int m0 = (tile / ntn) * G::BM;
-    const int n0 = (tile % ntn) * BN;
+    int tm_idx, tn_idx;
+    {
+        constexpr int SR = 8;
+        const int per_sr = SR * ntn;
+        const int sr = tile / per_sr, rem = tile - sr * per_sr;
+        const int rows_here = (ntm - sr * SR) < SR ? (ntm - sr * SR) : SR;   // last super-row may be short
+        tn_idx = rem / rows_here;
+        tm_idx = sr * SR + (rem - tn_idx * rows_here);
+    }
+    const int m0 = tm_idx * G::BM;
+    const int n0 = tn_idx * BN;
 
     // operand order: swapped => lane owns 4 consecutive columns of a row; natural => 4 consecutive rows of a column
     bool swapped = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID);
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < G::TM; ++i) a[i] = read_frag(st, wm * G::WROWS + i * 32 + l31, kc);
 #pragma unroll
-        for (int j = 0; j < G::TN; ++j) b[j] = read_frag(st + G::A_BYTES, wn * 64 + j * 32 + l31, kc);
+        for (int j = 0; j < G::TN; ++j) b[j] = read_frag(st + G::A_BYTES, wn * G::WCOLS + j * 32 + l31, kc);
     };
 
     issue(0);
@@ -304,8 +318,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     }
 
     const int row0 = m0 + wm * G::WROWS;          // first global row of this wave's sub-tile
-    const int col0 = n0 + wn * 64;                // first global column
-    const bool wide_ok = (p.N % 8 == 0) && (col0 + 64 <= p.N);
+    const int col0 = n0 + wn * G::WCOLS;          // first global column
+    static_assert(G::WCOLS == 64 || EPI == EPI_BIAS_RESID, "96-column wave tiles: residual epilogue only");
 
     if constexpr (EPI == EPI_F32) {
         // debug / test path: direct stores, natural layout (col = lane & 31, row = (r&3) + 8(r>>2) + 4 hi)
@@ -327,8 +341,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         char* ws = smem + wid * (G::LDS_BYTES / 8);
 
         if constexpr (EPI == EPI_BIAS_RESID) {
-            // x[row, col] += acc + bias[col]; one 32-row MFMA tile-row per pass through LDS (fp32, pitch 272 B)
-            constexpr int P = 64 * 4 + 16;
+            // x[row, col] += acc + bias[col]; one 32-row MFMA tile-row per pass through LDS (fp32, padded pitch)
+            constexpr int P = G::WCOLS * 4 + 16;
+            constexpr int CH = G::WCOLS / 4;               // 16-B chunks per row
 #pragma unroll
             for (int i = 0; i < G::TM; ++i) {
 #pragma unroll
@@ -344,9 +359,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                         *reinterpret_cast<float4*>(ws + l31 * P + cl * 4) = v;
                     }
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
+                for (int it = 0; it < 32 * CH / 64; ++it) {
                     const int idx = it * 64 + lane;
-                    const int rl = idx >> 4, ch = idx & 15;
+                    const int rl = idx / CH, ch = idx - rl * CH;
                     const float4 v = *reinterpret_cast<const float4*>(ws + rl * P + ch * 16);
                     const int row = row0 + i * 32 + rl, col = col0 + ch * 4;
                     if (row < p.M && col < p.N) {
@@ -357,7 +372,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                     }
                 }
             }
-        } else {
+        } else if constexpr (G::WCOLS == 64) {
             // bf16 outputs
             const bool to_vt = (EPI == EPI_QKV) && !swapped;
             if (!to_vt) {
@@ -426,7 +441,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 }
             }
         }
-        (void)wide_ok;
     }
 }
 
@@ -445,12 +459,16 @@ void launch256(const GemmParams& p, int epilogue, hipStream_t s) {
         }                                                                                             \
         hipLaunchKernelGGL((gemm256_kernel<BN, E>), grid, block, G::LDS_BYTES, s, p);                 \
     } while (0)
-    switch (epilogue) {
-        case EPI_F32: TLD_L256(EPI_F32); break;
-        case EPI_QKV: TLD_L256(EPI_QKV); break;
-        case EPI_BIAS_BF16: TLD_L256(EPI_BIAS_BF16); break;
-        case EPI_BIAS_RESID: TLD_L256(EPI_BIAS_RESID); break;
-        default: break;
+    if constexpr (BN == 192) {
+        TLD_L256(EPI_BIAS_RESID);
+    } else {
+        switch (epilogue) {
+            case EPI_F32: TLD_L256(EPI_F32); break;
+            case EPI_QKV: TLD_L256(EPI_QKV); break;
+            case EPI_BIAS_BF16: TLD_L256(EPI_BIAS_BF16); break;
+            case EPI_BIAS_RESID: TLD_L256(EPI_BIAS_RESID); break;
+            default: break;
+        }
     }
 #undef TLD_L256
 }
@@ -468,12 +486,18 @@ static int gemm_variant() {
 
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s) {
     if (gemm_variant() == 256 && p.K % 64 == 0) {
-        // BN = 256 unless that leaves the last round of workgroups mostly empty on 256 CUs
+        // BN = 256 unless that leaves the last round of workgroups mostly empty on 256 CUs; then prefer the
+        // widest tile whose workgroup count is a whole number of rounds (192 for the residual epilogue), else 128.
         const long ntm = (p.M + 255) / 256;
         const long blocks256 = ntm * ((p.N + 255) / 256);
         const bool narrow = (p.N % 256 != 0) || (blocks256 % 256 != 0 && blocks256 < 3 * 256);
         static const char* force = getenv("TLD_GEMM_BN");
-        if (force ? !strcmp(force, "128") : narrow) launch256<128>(p, epilogue, s);
+        int bn = narrow ? 128 : 256;
+        if (narrow && epilogue == EPI_BIAS_RESID && p.N % 192 == 0 && (ntm * (p.N / 192)) % 256 == 0) bn = 192;
+        if (force) bn = atoi(force);
+        if (bn == 192 && (epilogue != EPI_BIAS_RESID || p.N % 192)) bn = 128;
+        if (bn == 192) launch256<192>(p, epilogue, s);
+        else if (bn == 128) launch256<128>(p, epilogue, s);
         else launch256<256>(p, epilogue, s);
         return;
     }
