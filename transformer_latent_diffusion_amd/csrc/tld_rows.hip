@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const resid_t* __re
 // contribution in bwq).  The sub-block therefore needs no GEMM: per row it is 12 dot products of
 // the centred row against LDS-resident vectors, a sigmoid per head, and a blend of the two value rows.
 template <int NJ>
-__global__ __launch_bounds__(256) void cross_row_kernel(CrossRowParams p, int rows_per_block) {
+__global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int d = NJ * 128, H = NJ * 2;
     float* wd = reinterpret_cast<float*>(smem);          // [H][d]  wq_label - wq_noise (gamma folded)
@@ -157,80 +157,130 @@ __global__ __launch_bounds__(256) void cross_row_kernel(CrossRowParams p, int ro
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const bool upper = lane >= 32;
-    const int rows_per_wave = rows_per_block / 4;
-    for (int rr = 0; rr < rows_per_wave; ++rr) {
-        const size_t row = (size_t)b * p.ntok + r0 + wid * rows_per_wave + rr;
-        float2 v[NJ];
-        float s = 0.f;
+    const int rows_per_wave = rows_per_block / 4;            // even
+    const size_t wrow0 = (size_t)b * p.ntok + r0 + wid * rows_per_wave;
+
+    // Two rows per wave at a time (independent reduction chains fill the DPP wait states), with the next
+    // pair's HBM loads issued before the current pair is processed.
+    float2 xr[2][NJ];
+    bf16x2 ar[2][NJ];
+    auto fetch = [&](size_t row, float2 (&xv)[NJ], bf16x2 (&av)[NJ]) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = j * 128 + 2 * lane;
-            const float2 xv = *reinterpret_cast<const float2*>(p.x + row * d + n);
-            const bf16x2 av = *reinterpret_cast<const bf16x2*>(p.att + row * d + n);
-            v[j].x = xv.x + (float)av[0];                   // x = SA(LN1 x) + x
-            v[j].y = xv.y + (float)av[1];
-            s += v[j].x + v[j].y;
-            if (p.sa_out) *reinterpret_cast<float2*>(p.sa_out + row * d + n) = v[j];
+            xv[j] = *reinterpret_cast<const float2*>(p.x + row * d + n);
+            av[j] = *reinterpret_cast<const bf16x2*>(p.att + row * d + n);
         }
-        const float mean = wave_sum(s) / (float)d;
-        float2 c[NJ];
-        float q = 0.f;
+    };
+    fetch(wrow0, xr[0], ar[0]);
+    fetch(wrow0 + 1, xr[1], ar[1]);
+    for (int rr = 0; rr < rows_per_wave; rr += 2) {
+        float2 v[2][NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            c[j].x = v[j].x - mean; c[j].y = v[j].y - mean;
-            q += c[j].x * c[j].x + c[j].y * c[j].y;
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                v[u][j].x = xr[u][j].x + (float)ar[u][j][0];        // x = SA(LN1 x) + x
+                v[u][j].y = xr[u][j].y + (float)ar[u][j][1];
+            }
+        const size_t row = wrow0 + rr;
+        if (rr + 2 < rows_per_wave) {
+            fetch(row + 2, xr[0], ar[0]);
+            fetch(row + 3, xr[1], ar[1]);
         }
-        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
+        if (p.sa_out) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    *reinterpret_cast<float2*>(p.sa_out + (row + u) * d + j * 128 + 2 * lane) = v[u][j];
+        }
+        float s[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) s[u] += v[u][j].x + v[u][j].y;
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) mean[u] = wave_sum(s[u]) / (float)d;
+        float2 c[2][NJ];
+        float q[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                c[u][j].x = v[u][j].x - mean[u]; c[u][j].y = v[u][j].y - mean[u];
+                q[u] += c[u][j].x * c[u][j].x + c[u][j].y * c[u][j].y;
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) rstd[u] = 1.0f / sqrtf(wave_sum(q[u]) / (float)d + kLnEps);
 
         // per-head logit difference -> sigmoid weight of the label token.
         // lane's features of group j belong to head 2j + (lane >> 5)
-        float plab[NJ];
+        float plab[2][NJ];
 #pragma unroll
         for (int hh = 0; hh < NJ; ++hh) {
-            float part0 = 0.f, part1 = 0.f;
+            float part[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
             const float* w0 = wd + (2 * hh) * d + 2 * lane;
             const float* w1 = w0 + d;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const float2 a = *reinterpret_cast<const float2*>(w0 + j * 128);
                 const float2 e = *reinterpret_cast<const float2*>(w1 + j * 128);
-                part0 = fmaf(c[j].x, a.x, fmaf(c[j].y, a.y, part0));
-                part1 = fmaf(c[j].x, e.x, fmaf(c[j].y, e.y, part1));
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    part[u][0] = fmaf(c[u][j].x, a.x, fmaf(c[u][j].y, a.y, part[u][0]));
+                    part[u][1] = fmaf(c[u][j].x, e.x, fmaf(c[u][j].y, e.y, part[u][1]));
+                }
             }
-            const float d0 = wave_sum(part0) * rstd + bw[2 * hh];
-            const float d1 = wave_sum(part1) * rstd + bw[2 * hh + 1];
-            const float dl = upper ? d1 : d0;
-            plab[hh] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-dl * 1.44269504088896340736f));
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float d0 = wave_sum(part[u][0]) * rstd[u] + bw[2 * hh];
+                const float d1 = wave_sum(part[u][1]) * rstd[u] + bw[2 * hh + 1];
+                const float dl = upper ? d1 : d0;
+                plab[u][hh] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-dl * 1.44269504088896340736f));
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep the next head pair's 2 x NJ LDS reads from being hoisted (VGPRs)
         }
         // x += p_noise v_n + p_label v_l ; then LN3
-        float s3 = 0.f;
+        float s3[2] = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = j * 128 + 2 * lane;
             const float2 a = *reinterpret_cast<const float2*>(vn + n);
             const float2 dd = *reinterpret_cast<const float2*>(vdiff + n);
-            v[j].x += fmaf(plab[j], dd.x, a.x);
-            v[j].y += fmaf(plab[j], dd.y, a.y);
-            *reinterpret_cast<float2*>(p.x + row * d + n) = v[j];
-            s3 += v[j].x + v[j].y;
-        }
-        const float mean3 = wave_sum(s3) / (float)d;
-        float q3 = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            v[j].x -= mean3; v[j].y -= mean3;
-            q3 += v[j].x * v[j].x + v[j].y * v[j].y;
+            for (int u = 0; u < 2; ++u) {
+                v[u][j].x += fmaf(plab[u][j], dd.x, a.x);
+                v[u][j].y += fmaf(plab[u][j], dd.y, a.y);
+                *reinterpret_cast<float2*>(p.x + (row + u) * d + n) = v[u][j];
+                s3[u] += v[u][j].x + v[u][j].y;
+            }
         }
-        const float rstd3 = 1.0f / sqrtf(wave_sum(q3) / (float)d + kLnEps);
+        float mean3[2], rstd3[2], q3[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) mean3[u] = wave_sum(s3[u]) / (float)d;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                v[u][j].x -= mean3[u]; v[u][j].y -= mean3[u];
+                q3[u] += v[u][j].x * v[u][j].x + v[u][j].y * v[u][j].y;
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) rstd3[u] = 1.0f / sqrtf(wave_sum(q3[u]) / (float)d + kLnEps);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = j * 128 + 2 * lane;
             const float2 gg = *reinterpret_cast<const float2*>(p.ln3_w + n);
             const float2 bb = *reinterpret_cast<const float2*>(p.ln3_b + n);
-            bf16x2 o;
-            o[0] = (bf16)(v[j].x * rstd3 * gg.x + bb.x);
-            o[1] = (bf16)(v[j].y * rstd3 * gg.y + bb.y);
-            *reinterpret_cast<bf16x2*>(p.xn3 + row * d + n) = o;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                bf16x2 o;
+                o[0] = (bf16)(v[u][j].x * rstd3[u] * gg.x + bb.x);
+                o[1] = (bf16)(v[u][j].y * rstd3[u] * gg.y + bb.y);
+                *reinterpret_cast<bf16x2*>(p.xn3 + (row + u) * d + n) = o;
+            }
         }
     }
 }
@@ -302,65 +352,83 @@ __global__ __launch_bounds__(256) void update_kernel(UpdateParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// One thread owns 8 channels of one image row (b, i) and slides a 3x3 window along j: 3 new 16-B
-// loads and one 16-B store per output, weights (72 + 8 floats) stay in registers.
+// Depthwise 3x3 + bias + exact GELU.  One workgroup = one sample x 64 channels: the whole g x g image
+// slab (g*g tokens x 128 B) is pulled into LDS once with 16-B coalesced loads, so HBM/L2 see every input
+// exactly once (the register-window version re-read each row three times through L2).  Thread (row i,
+// channel quad) then slides a 3x3 fp32 window along j: 3 ds_read_b64 + 36 FMAs + 4 GELUs + one 8-B
+// store per position; weights stay in registers.  GELU uses the Abramowitz-Stegun erf (1.5e-7).
+constexpr int DW_CB = 64;                       // channels per workgroup
 __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const bf16* __restrict__ in, bf16* __restrict__ out,
                                                           const float* __restrict__ w9c,
                                                           const float* __restrict__ bias, int batch,
                                                           int g, int C) {
-    const int c8n = C / 8;
-    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t total = (size_t)batch * g * c8n;
-    if (tid >= total) return;
-    const int c8 = (int)(tid % c8n);
-    const int bi = (int)(tid / c8n);
-    const int b = bi / g, i = bi - b * g;
-    const int c0 = c8 * 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [g*g tokens][64 ch] bf16
+    const int nchunk = C / DW_CB;
+    const int b = blockIdx.x / nchunk, cc = blockIdx.x - b * nchunk;
+    const int ntok = g * g;
+    const bf16* src = in + (size_t)b * ntok * C + cc * DW_CB;
+    for (int idx = threadIdx.x; idx < ntok * 8; idx += 256) {       // 8 x 16-B pieces per token
+        const int t = idx >> 3, q = idx & 7;
+        *reinterpret_cast<uint4*>(smem + t * 128 + q * 16) =
+            *reinterpret_cast<const uint4*>(src + (size_t)t * C + q * 8);
+    }
+    const int cq = threadIdx.x & 15;             // channel quad within the 64-channel slab
+    const int c0 = cc * DW_CB + cq * 4;
+    float4 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const float4*>(w9c + (size_t)k * C + c0);
+    const float4 bs = *reinterpret_cast<const float4*>(bias + c0);
+    __syncthreads();
 
-    float w[9][8], bs[8];
+    for (int i = threadIdx.x >> 4; i < g; i += 16) {
+        const bool up_ok = i > 0, dn_ok = i + 1 < g;
+        auto load_col = [&](int j, float4 (&col)[3]) {
+            const bool jok = j >= 0 && j < g;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const float4 lo = *reinterpret_cast<const float4*>(w9c + (size_t)k * C + c0);
-        const float4 hi = *reinterpret_cast<const float4*>(w9c + (size_t)k * C + c0 + 4);
-        w[k][0] = lo.x; w[k][1] = lo.y; w[k][2] = lo.z; w[k][3] = lo.w;
-        w[k][4] = hi.x; w[k][5] = hi.y; w[k][6] = hi.z; w[k][7] = hi.w;
-    }
-    {
-        const float4 lo = *reinterpret_cast<const float4*>(bias + c0);
-        const float4 hi = *reinterpret_cast<const float4*>(bias + c0 + 4);
-        bs[0] = lo.x; bs[1] = lo.y; bs[2] = lo.z; bs[3] = lo.w;
-        bs[4] = hi.x; bs[5] = hi.y; bs[6] = hi.z; bs[7] = hi.w;
-    }
-    const bf16* base = in + ((size_t)b * g * g) * C + c0;
-    auto load_col = [&](int j, bf16x8 (&col)[3]) {
+            for (int du = 0; du < 3; ++du) {
+                const bool ok = jok && (du == 1 || (du == 0 ? up_ok : dn_ok));
+                if (ok) {
+                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(smem + ((i + du - 1) * g + j) * 128 + cq * 8);
+                    col[du] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+                } else {
+                    col[du] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        bf16* dst = out + ((size_t)b * ntok + (size_t)i * g) * C + c0;
+        // one output position from the three window columns (L = j-1, M = j, R = j+1); three independent
+        // accumulation chains (one per image row) keep the packed-FMA pipeline free of dependency stalls
+        auto emit = [&](const float4 (&L)[3], const float4 (&Mc)[3], const float4 (&R)[3], int j) {
+            float4 part[3];
 #pragma unroll
-        for (int du = 0; du < 3; ++du) {
-            const int ii = i + du - 1;
-            if (ii >= 0 && ii < g && j >= 0 && j < g)
-                col[du] = *reinterpret_cast<const bf16x8*>(base + ((size_t)ii * g + j) * C);
-            else
-#pragma unroll
-                for (int e = 0; e < 8; ++e) col[du][e] = (bf16)0.f;
+            for (int du = 0; du < 3; ++du) {
+                const float4 w0 = w[du * 3 + 0], w1 = w[du * 3 + 1], w2 = w[du * 3 + 2];
+                part[du].x = fmaf(w2.x, R[du].x, fmaf(w1.x, Mc[du].x, w0.x * L[du].x));
+                part[du].y = fmaf(w2.y, R[du].y, fmaf(w1.y, Mc[du].y, w0.y * L[du].y));
+                part[du].z = fmaf(w2.z, R[du].z, fmaf(w1.z, Mc[du].z, w0.z * L[du].z));
+                part[du].w = fmaf(w2.w, R[du].w, fmaf(w1.w, Mc[du].w, w0.w * L[du].w));
+            }
+            const float ax = (part[0].x + part[1].x) + (part[2].x + bs.x);
+            const float ay = (part[0].y + part[1].y) + (part[2].y + bs.y);
+            const float az = (part[0].z + part[1].z) + (part[2].z + bs.z);
+            const float aw = (part[0].w + part[1].w) + (part[2].w + bs.w);
+            bf16x4 o;
+            o[0] = (bf16)gelu_erf_fast(ax); o[1] = (bf16)gelu_erf_fast(ay);
+            o[2] = (bf16)gelu_erf_fast(az); o[3] = (bf16)gelu_erf_fast(aw);
+            *reinterpret_cast<bf16x4*>(dst + (size_t)j * C) = o;
+        };
+        // the window rotates through three named column buffers, so no register copies are needed
+        float4 c0v[3], c1v[3], c2v[3];
+        load_col(-1, c0v);
+        load_col(0, c1v);
+        int j = 0;
+        for (; j + 3 <= g; j += 3) {
+            load_col(j + 1, c2v); emit(c0v, c1v, c2v, j);
+            load_col(j + 2, c0v); emit(c1v, c2v, c0v, j + 1);
+            load_col(j + 3, c1v); emit(c2v, c0v, c1v, j + 2);
         }
-    };
-    bf16x8 win[3][3];     // win[dv][du]: column j-1+dv, row i-1+du
-    load_col(-1, win[0]);
-    load_col(0, win[1]);
-    for (int j = 0; j < g; ++j) {
-        load_col(j + 1, win[2]);
-        bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float acc = bs[e];
-#pragma unroll
-            for (int du = 0; du < 3; ++du)
-#pragma unroll
-                for (int dv = 0; dv < 3; ++dv) acc += w[du * 3 + dv][e] * (float)win[dv][du][e];
-            o[e] = (bf16)gelu_erf_fast(acc);
-        }
-        *reinterpret_cast<bf16x8*>(out + (((size_t)b * g + i) * g + j) * C + c0) = o;
-#pragma unroll
-        for (int du = 0; du < 3; ++du) { win[0][du] = win[1][du]; win[1][du] = win[2][du]; }
+        if (j < g) { load_col(j + 1, c2v); emit(c0v, c1v, c2v, j); ++j; }
+        if (j < g) { load_col(j + 1, c0v); emit(c1v, c2v, c0v, j); }
     }
 }
 
@@ -390,7 +458,7 @@ void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf1
 }
 
 void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
-    const int rpb = (p.ntok % 64 == 0) ? 64 : 32;
+    const int rpb = 32;                 // 4 waves x 8 rows; ~43 KB of LDS per workgroup -> 3 workgroups per CU
     const int lds = (p.heads * p.d + 2 * p.d + p.heads) * (int)sizeof(float);
     dim3 grid(p.batch * (p.ntok / rpb));
     TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(cross_row_kernel<NJ>, grid, dim3(256), lds, s, p, rpb));
@@ -410,8 +478,13 @@ void launch_update(const UpdateParams& p, hipStream_t s) {
 
 void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c, const float* bias, int batch, int grid,
                         int channels, hipStream_t s) {
-    const size_t total = (size_t)batch * grid * (channels / 8);
-    hipLaunchKernelGGL(dwconv_gelu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out,
+    const int lds = grid * grid * 128;
+    static bool once = false;
+    if (!once) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_gelu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once = true;
+    }
+    hipLaunchKernelGGL(dwconv_gelu_kernel, dim3((unsigned)(batch * (channels / DW_CB))), dim3(256), lds, s, in, out,
                        w9c, bias, batch, grid, channels);
 }
 
