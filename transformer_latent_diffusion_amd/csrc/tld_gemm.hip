@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 // BN=192 -> 4 x 2, 64 x 96 (residual-add epilogue only: N = 768 then fills 256 CUs in exactly 2 rounds).
 template <int BN>
 struct G256 {
-    static constexpr int BM = 256, BK = 64, STAGES = 2;
+    static constexpr int BM = 256, BK = 64;
+    static constexpr int STAGES = (BN == 128) ? 3 : 2;          // (256+128)*128 B = 48 KiB per stage -> 3 fit
     static constexpr int WN = (BN == 256) ? 4 : 2, WMc = 8 / WN;   // waves along N / M
     static constexpr int WROWS = BM / WMc;                      // rows per wave: 128 or 64
     static constexpr int WCOLS = BN / WN;                       // cols per wave: 64 (BN 256/128) or 96 (BN 192)
@@ -192,6 +193,7 @@ struct G256 {
     static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
     static constexpr int A_PIECES = BM / 8 / 8, B_PIECES = BN / 8 / 8;     // 1-KiB DMA pieces per wave per tile
+    static constexpr int LOADS_PER_TILE = A_PIECES + B_PIECES;
 };
 
 template <int PIECES>
@@ -216,6 +218,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else static_assert(N < 0, "unsupported vmcnt");
 }
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 
     const int nk = p.K / G::BK;
     auto issue = [&](int t) {
-        char* st = smem + (t & 1) * G::STAGE_BYTES;
+        char* st = smem + (t % G::STAGES) * G::STAGE_BYTES;
         stage64<G::A_PIECES>(p.A, p.lda, m0, p.M, t * G::BK, st, wid, lane);
         stage64<G::B_PIECES>(p.W, p.ldw, n0, p.N, t * G::BK, st + G::A_BYTES, wid, lane);
     };
@@ -281,7 +284,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         for (int j = 0; j < G::TN; ++j) b[j] = read_frag(st + G::A_BYTES, wn * G::WCOLS + j * 32 + l31, kc);
     };
 
+    // prologue: STAGES-1 tiles in flight
     issue(0);
+    if constexpr (G::STAGES == 3) { if (nk > 1) issue(1); }
     bf16x8 a0[G::TM], b0[G::TN], a1[G::TM], b1[G::TN];
     auto kloop = [&](auto swp) {
         constexpr bool SW = decltype(swp)::value;
@@ -295,11 +300,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
                 }
         };
         for (int t = 0; t < nk; ++t) {
-            wait_vmcnt<0>();                       // this wave's pieces of tile t have landed
-            __builtin_amdgcn_s_barrier();          // ... everybody's; and stage (t+1)&1 is no longer read
-            const char* st = smem + (t & 1) * G::STAGE_BYTES;
+            // this wave's pieces of tile t have landed (with 3 stages tile t+1 may stay in flight: counted vmcnt)
+            if (G::STAGES == 3 && t + 1 < nk) wait_vmcnt<G::LOADS_PER_TILE>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();          // ... everybody's; and the stage of tile t-1 is no longer read
+            const char* st = smem + (t % G::STAGES) * G::STAGE_BYTES;
             load_frags(st, 0, a0, b0);
-            if (t + 1 < nk) issue(t + 1);          // DMA address math overlaps the first fragment reads
+            if (t + G::STAGES - 1 < nk) issue(t + G::STAGES - 1);   // DMA address math overlaps the first fragment reads
             load_frags(st, 1, a1, b1);
             mma(a0, b0);
             load_frags(st, 2, a0, b0);
