@@ -33,6 +33,7 @@ PER_GPU_IMAGES = 64
 N_ITER = 35
 CFG = 6.0
 GFLOP_PER_SAMPLE_FWD = 46.163      # SURVEY.md Appendix B (N=256, d=768, L=12), reference op count
+GFLOP_BY_IMAGE_SIZE = {32: 46.163, 64: 213.466, 128: 1317.543}   # Appendix B, per sample-forward
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -83,6 +84,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images-per-gpu", type=int, default=PER_GPU_IMAGES)
+    ap.add_argument("--image-size", type=int, default=32, choices=(32, 64, 128),
+                    help="latent size: 32 = C1/C2 (headline), 64 = C3 shape, 128 = C4 shape (bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of the GEMM classes")
     args = ap.parse_args()
@@ -105,7 +108,10 @@ def main():
     from transformer_latent_diffusion_amd.sharded import generate_latents_sharded
     from transformer_latent_diffusion_amd.weights import synth_state_dict
 
-    cfg = config_100m()
+    cfg = config_100m(args.image_size)
+    S = args.image_size
+    gflop_fwd = GFLOP_BY_IMAGE_SIZE[S]
+    ntok = (S // 2) ** 2
     sd = synth_state_dict(cfg, 5)
     model = Denoiser(**asdict(cfg)).to(dev)
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
@@ -115,12 +121,12 @@ def main():
 
     total = B * world
     g = torch.Generator().manual_seed(11)
-    x_T = torch.randn(total, 4, 32, 32, generator=g).to(dev)                # resident before timing
+    x_T = torch.randn(total, 4, S, S, generator=g).to(dev)                # resident before timing
     labels = (torch.randn(total, 768, generator=torch.Generator().manual_seed(12)) * 0.5).to(dev)
 
     def one_step():
         return generate_latents_sharded(gen, labels, n_iter=N_ITER, num_imgs=total, class_guidance=CFG,
-                                        img_size=32, sharp_f=0.0, bright_f=0.0, exponent=1, seeds=x_T)
+                                        img_size=S, sharp_f=0.0, bright_f=0.0, exponent=1, seeds=x_T)
 
     def fence():
         if world > 1:
@@ -168,16 +174,16 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "C1: 100M-param denoiser (d=768, L=12), 32x32x4 latents, 35 steps + CFG 6, "
+            "config": {"workload": f"{ {32: 'C1', 64: 'C3-shape', 128: 'C4-shape (bf16)'}[S]}: 100M-param denoiser (d=768, L=12), {S}x{S}x4 latents, 35 steps + CFG 6, "
                                    f"DPM-Solver++(2M), {B} images/GPU (model batch {2 * B})",
                        "images_per_gpu": B, "global_batch": total, "n_iter": N_ITER, "class_guidance": CFG,
                        "parallelism": f"dp{world} (sample-sharded, one all-gather)" if world > 1 else "single GPU"},
             "ms_per_denoise_step": ms_per_step / N_ITER,
-            "model_tflops": value * 2 * N_ITER * GFLOP_PER_SAMPLE_FWD / 1e3,
-            "frac_of_bf16_mfma_peak": value * 2 * N_ITER * GFLOP_PER_SAMPLE_FWD / 1e3 / (MFMA_PEAK_TFLOPS * world),
+            "model_tflops": value * 2 * N_ITER * gflop_fwd / 1e3,
+            "frac_of_bf16_mfma_peak": value * 2 * N_ITER * gflop_fwd / 1e3 / (MFMA_PEAK_TFLOPS * world),
         }
         if prof:
-            M = 2 * B * 256
+            M = 2 * B * ntok
             dom = dom_cls
             ms, n = prof[dom]
             avg_s = ms / max(n, 1) / 1e3
@@ -196,7 +202,7 @@ def main():
                 "note": "dominant class timed with HIP events inside the timed region; the other classes on one untimed pass",
                 "gemm_aggregate_tflops": tot_f / tot_t / 1e12,
             }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and S == 32:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -18,6 +18,9 @@ Fixtures:
   g4_wide1_forward.npz    d=768, L=1, image_size=32: one 100M-width layer, B=2
   g5_100m.npz             full 100M model: forward B=2; 35-step CFG=6 DPM-2M end latent, B=1
   g6_schedule.npz         noise_levels / rs (float64) for several n_iter, exponent
+  g7_100m_512px.npz       BASELINE config C3 shape: 100M model with image_size=64 (N=1024 tokens), forward B=1
+  g8_100m_1024px.npz      BASELINE config C4 shape: image_size=128 (N=4096 tokens), forward B=1 (bf16 path; the
+                          reference has no fp8 and no pos-embed interpolation code -- SURVEY.md section 0.5)
 """
 import os
 import sys
@@ -244,3 +247,5 @@ if __name__ == "__main__":
     forward_fixture("g4_wide1_forward.npz", c4, 4, 2, 44)
     schedule_fixture()
     big_fixture()
+    forward_fixture("g7_100m_512px.npz", config_100m(64), 7, 1, 77)
+    forward_fixture("g8_100m_1024px.npz", config_100m(128), 8, 1, 88)

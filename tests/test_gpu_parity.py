@@ -76,7 +76,8 @@ def test_g1_stages_tiny32():
     assert rel_rms(out, g["x0"]) <= FWD_TOL, rel_rms(out, g["x0"])
 
 
-@pytest.mark.parametrize("name", ["g3_tiny16_forward.npz", "g4_wide1_forward.npz", "g5_100m.npz"])
+@pytest.mark.parametrize("name", ["g3_tiny16_forward.npz", "g4_wide1_forward.npz", "g5_100m.npz",
+                                  "g7_100m_512px.npz", "g8_100m_1024px.npz"])   # g7/g8: BASELINE C3 / C4 shapes (N = 1024 / 4096)
 def test_forward_vs_golden(name):
     g = load_golden(name)
     cfg, sd, m = _engine(g)

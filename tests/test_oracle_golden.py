@@ -28,7 +28,7 @@ def test_g1_tiny32_forward_and_stages():
     assert out.shape == g["x"].shape
 
 
-@pytest.mark.parametrize("name", ["g3_tiny16_forward.npz", "g4_wide1_forward.npz"])
+@pytest.mark.parametrize("name", ["g3_tiny16_forward.npz", "g4_wide1_forward.npz", "g7_100m_512px.npz"])
 def test_forward_fixtures(name):
     g = load_golden(name)
     cfg, m = _model(g)

@@ -16,6 +16,10 @@
 #include <cstring>
 #include <type_traits>
 
+#ifndef TLD_GLDS_AUX
+#define TLD_GLDS_AUX 0      // cache-policy bits of the tile DMA (experiment knob: 2 = nt)
+#endif
+
 namespace tld {
 
 namespace {
@@ -209,7 +213,7 @@ __device__ __forceinline__ void stage64(const bf16* __restrict__ g, int ld, int 
         gr = gr < row_max ? gr : row_max - 1;
         const bf16* src = g + (size_t)gr * ld + k0 + clog * 8;
         char* dst = lds_tile + piece * 1024;                    // wave-uniform; lane i lands at +16*i
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, TLD_GLDS_AUX);
     }
 }
 

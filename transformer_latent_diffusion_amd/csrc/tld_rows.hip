@@ -432,6 +432,76 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const bf16* __restrict
     }
 }
 
+// Same computation for grids larger than 16x16 (512 / 1024 px latents): one workgroup = one sample x 64
+// channels x one 16x16 spatial tile; the tile plus a one-token halo (18 x 18 tokens, zero outside the image)
+// is staged in LDS, then the sliding-window loop runs without bounds checks.
+__global__ __launch_bounds__(256) void dwconv_gelu_tiled_kernel(const bf16* __restrict__ in, bf16* __restrict__ out,
+                                                                const float* __restrict__ w9c,
+                                                                const float* __restrict__ bias, int batch,
+                                                                int g, int C) {
+    constexpr int T = 16, TP = T + 2;
+    __shared__ __attribute__((aligned(16))) char tile[TP * TP * 128];
+    const int nchunk = C / DW_CB;
+    const int tiles = (g + T - 1) / T;
+    int bid = blockIdx.x;
+    const int cc = bid % nchunk; bid /= nchunk;
+    const int tx = bid % tiles; bid /= tiles;
+    const int ty = bid % tiles;
+    const int b = bid / tiles;
+    const int i0 = ty * T - 1, j0 = tx * T - 1;
+    const bf16* src = in + (size_t)b * g * g * C + cc * DW_CB;
+    for (int idx = threadIdx.x; idx < TP * TP * 8; idx += 256) {
+        const int t = idx >> 3, q = idx & 7;
+        const int li = t / TP, lj = t - li * TP;
+        const int gi = i0 + li, gj = j0 + lj;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (gi >= 0 && gi < g && gj >= 0 && gj < g)
+            v = *reinterpret_cast<const uint4*>(src + ((size_t)gi * g + gj) * C + q * 8);
+        *reinterpret_cast<uint4*>(tile + t * 128 + q * 16) = v;
+    }
+    const int cq = threadIdx.x & 15;
+    const int c0 = cc * DW_CB + cq * 4;
+    float4 w[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const float4*>(w9c + (size_t)k * C + c0);
+    const float4 bs = *reinterpret_cast<const float4*>(bias + c0);
+    __syncthreads();
+    const int li = threadIdx.x >> 4;                       // output row inside the tile (0..15)
+    const int gi = ty * T + li;
+    if (gi >= g) return;
+    auto col = [&](int lj, float4 (&c)[3]) {               // lj: halo-tile column index 0..17
+#pragma unroll
+        for (int du = 0; du < 3; ++du) {
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>(tile + ((li + du) * TP + lj) * 128 + cq * 8);
+            c[du] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+        }
+    };
+    float4 cL[3], cM[3], cR[3];
+    col(0, cL); col(1, cM);
+    for (int lj = 0; lj < T; ++lj) {
+        const int gj = tx * T + lj;
+        if (gj >= g) break;
+        col(lj + 2, cR);
+        float4 part[3];
+#pragma unroll
+        for (int du = 0; du < 3; ++du) {
+            const float4 w0 = w[du * 3 + 0], w1 = w[du * 3 + 1], w2 = w[du * 3 + 2];
+            part[du].x = fmaf(w2.x, cR[du].x, fmaf(w1.x, cM[du].x, w0.x * cL[du].x));
+            part[du].y = fmaf(w2.y, cR[du].y, fmaf(w1.y, cM[du].y, w0.y * cL[du].y));
+            part[du].z = fmaf(w2.z, cR[du].z, fmaf(w1.z, cM[du].z, w0.z * cL[du].z));
+            part[du].w = fmaf(w2.w, cR[du].w, fmaf(w1.w, cM[du].w, w0.w * cL[du].w));
+        }
+        bf16x4 o;
+        o[0] = (bf16)gelu_erf_fast((part[0].x + part[1].x) + (part[2].x + bs.x));
+        o[1] = (bf16)gelu_erf_fast((part[0].y + part[1].y) + (part[2].y + bs.y));
+        o[2] = (bf16)gelu_erf_fast((part[0].z + part[1].z) + (part[2].z + bs.z));
+        o[3] = (bf16)gelu_erf_fast((part[0].w + part[1].w) + (part[2].w + bs.w));
+        *reinterpret_cast<bf16x4*>(out + ((size_t)b * g * g + (size_t)gi * g + gj) * C + c0) = o;
+#pragma unroll
+        for (int du = 0; du < 3; ++du) { cL[du] = cM[du]; cM[du] = cR[du]; }
+    }
+}
+
 }  // namespace
 
 #define TLD_DISPATCH_NJ(nj, CALL)                                                                  \
@@ -478,12 +548,13 @@ void launch_update(const UpdateParams& p, hipStream_t s) {
 
 void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c, const float* bias, int batch, int grid,
                         int channels, hipStream_t s) {
-    const int lds = grid * grid * 128;
-    static bool once = false;
-    if (!once) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_gelu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        once = true;
+    if (grid > 16) {        // spatially tiled variant (halo in LDS)
+        const int tiles = (grid + 15) / 16;
+        hipLaunchKernelGGL(dwconv_gelu_tiled_kernel, dim3((unsigned)(batch * tiles * tiles * (channels / DW_CB))),
+                           dim3(256), 0, s, in, out, w9c, bias, batch, grid, channels);
+        return;
     }
+    const int lds = grid * grid * 128;
     hipLaunchKernelGGL(dwconv_gelu_kernel, dim3((unsigned)(batch * (channels / DW_CB))), dim3(256), lds, s, in, out,
                        w9c, bias, batch, grid, channels);
 }
