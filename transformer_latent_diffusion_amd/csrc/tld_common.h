@@ -82,6 +82,7 @@ struct GemmParams {
     int ntok, d;                  // EPI_QKV
     const float* bias;            // EPI_BIAS_*
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
+    int dbg_same_tile;            // experiment knob (tools/gemm_bench.py): 2 = no tile DMA inside the K loop
 };
 
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s);

@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -583,6 +584,7 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;
     g.c_f32 = res; g.ldc = N; g.out_bf16 = out; g.ldo = epilogue == EPI_QKV ? 2 * (N / 3) : N; g.vt = vt;
     g.ntok = ntok > 0 ? ntok : 1; g.d = N / 3; g.bias = bias; g.resid = res; g.ldr = N;
+    g.dbg_same_tile = getenv("TLD_GEMM_DBG") ? atoi(getenv("TLD_GEMM_DBG")) : 0;
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) launch_gemm(g, epilogue, nullptr);
