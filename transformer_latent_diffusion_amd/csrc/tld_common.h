@@ -82,10 +82,11 @@ struct GemmParams {
     int ntok, d;                  // EPI_QKV
     const float* bias;            // EPI_BIAS_*
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
-    int dbg_same_tile;            // experiment knob (tools/gemm_bench.py): 2 = no tile DMA inside the K loop
+    int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop
 };
 
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s);
+
 
 // self-attention over ntok tokens, head_dim 64: softmax(q k^T / 8) v -> att bf16 [M, d]
 void launch_attention(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads,

@@ -577,19 +577,21 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     HIP_TRY(hipMalloc(&A, (size_t)M * K * 2)); HIP_TRY(hipMalloc(&W, (size_t)N * K * 2));
     HIP_TRY(hipMalloc(&out, (size_t)M * N * 2)); HIP_TRY(hipMalloc(&vt, (size_t)M * N * 2));
     HIP_TRY(hipMalloc(&bias, (size_t)N * 4)); HIP_TRY(hipMalloc(&res, (size_t)M * N * 4));
-    launch_fill_bf16(A, (int64_t)M * K, 1u, 1.0f, nullptr);
-    launch_fill_bf16(W, (int64_t)N * K, 2u, 0.05f, nullptr);
+    const float zs = getenv("TLD_GEMM_ZERO") ? 0.0f : 1.0f;     // DVFS experiment: all-zero operands
+    launch_fill_bf16(A, (int64_t)M * K, 1u, 1.0f * zs, nullptr);
+    launch_fill_bf16(W, (int64_t)N * K, 2u, 0.05f * zs, nullptr);
     HIP_TRY(hipMemset(bias, 0, (size_t)N * 4)); HIP_TRY(hipMemset(res, 0, (size_t)M * N * 4));
     GemmParams g{};
     g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;
     g.c_f32 = res; g.ldc = N; g.out_bf16 = out; g.ldo = epilogue == EPI_QKV ? 2 * (N / 3) : N; g.vt = vt;
     g.ntok = ntok > 0 ? ntok : 1; g.d = N / 3; g.bias = bias; g.resid = res; g.ldr = N;
-    g.dbg_same_tile = getenv("TLD_GEMM_DBG") ? atoi(getenv("TLD_GEMM_DBG")) : 0;
+    g.dbg_no_dma = (getenv("TLD_GEMM_DBG") && atoi(getenv("TLD_GEMM_DBG")) == 2) ? 1 : 0;
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) launch_gemm(g, epilogue, nullptr);
+    auto run = [&]() { launch_gemm(g, epilogue, nullptr); };
+    for (int i = 0; i < 3; ++i) run();
     HIP_TRY(hipEventRecord(a, nullptr));
-    for (int i = 0; i < iters; ++i) launch_gemm(g, epilogue, nullptr);
+    for (int i = 0; i < iters; ++i) run();
     HIP_TRY(hipEventRecord(b, nullptr));
     HIP_TRY(hipEventSynchronize(b));
     float ms = 0.f;
