@@ -88,6 +88,9 @@ def main():
                     help="latent size: 32 = C1/C2 (headline), 64 = C3 shape, 128 = C4 shape (bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of the GEMM classes")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="plumbing test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,12 +99,15 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
     assert torch.cuda.is_available(), "bench.py measures the HIP engine; no HIP device is visible"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.same_device else local_rank)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from dataclasses import asdict
     from transformer_latent_diffusion_amd import Denoiser, DiffusionGenerator, config_100m

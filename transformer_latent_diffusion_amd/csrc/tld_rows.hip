@@ -17,70 +17,77 @@ namespace {
 
 
 // ------------------------------------------------------------------------------------------------
+// Workgroup = 64 token rows (16 per wave); the Linear(pd -> d) weight table [pd][d] fp32 (49 KB at d = 768)
+// is staged in LDS once per workgroup -- read per row from L1/L2 it made the kernel L1-bandwidth bound.
 template <int NJ>
 __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int d = NJ * 128;
+    float* wt = reinterpret_cast<float*>(smem);                  // [pd][d]
+    for (int i = threadIdx.x; i < p.pd * d / 4; i += 256)
+        reinterpret_cast<float4*>(wt)[i] = reinterpret_cast<const float4*>(p.lin_wt)[i];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));   // token row
-    if (row >= p.batch * p.ntok) return;
-    const int b = row / p.ntok, t = row - b * p.ntok;
-    const int ti = t / p.grid, tj = t - ti * p.grid;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pp = p.p * p.p, cpp = p.C * pp;
-
-    // the patch's C*p*p input values, one per lane (lane = (c, u, v))
-    float xin = 0.f;
-    if (lane < cpp) {
-        const int c = lane / pp, uv = lane - c * pp, u = uv / p.p, v = uv - u * p.p;
-        xin = p.x[(((size_t)(b % p.src_batch) * p.C + c) * p.S + (ti * p.p + u)) * p.S + (tj * p.p + v)];
-    }
-    // patchify conv: lane o < pd computes feature o
-    float pv = lane < p.pd ? p.conv_b[lane] : 0.f;
+    const int total = p.batch * p.ntok;
+    // per-lane constants
+    const float cb = lane < p.pd ? p.conv_b[lane] : 0.f;
     const float* cw = p.conv_w + (lane < p.pd ? lane : 0) * cpp;
-    for (int i = 0; i < cpp; ++i) {
-        const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xin), i));
-        pv = fmaf(cw[i], xv, pv);
-    }
-    if (lane >= p.pd) pv = 0.f;
-    // LN over pd
-    const float inv_pd = 1.0f / (float)p.pd;
-    const float mean1 = wave_sum(pv) * inv_pd;
-    const float dv = lane < p.pd ? pv - mean1 : 0.f;
-    const float rstd1 = 1.0f / sqrtf(wave_sum(dv * dv) * inv_pd + kLnEps);
-    float pn = 0.f;
-    if (lane < p.pd) pn = dv * rstd1 * p.ln1_w[lane] + p.ln1_b[lane];
+    const float g1 = lane < p.pd ? p.ln1_w[lane] : 0.f, b1 = lane < p.pd ? p.ln1_b[lane] : 0.f;
+    const int ic = lane / pp, iuv = lane - ic * pp, iu = iuv / p.p, iv = iuv - iu * p.p;   // lane = (c,u,v) for loads
+    constexpr int ROWS_PER_WAVE = 16;
+    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+        const int row = (blockIdx.x * 4 + wid) * ROWS_PER_WAVE + rr;
+        if (row >= total) return;
+        const int b = row / p.ntok, t = row - b * p.ntok;
+        const int ti = t / p.grid, tj = t - ti * p.grid;
+        float xin = 0.f;
+        if (lane < cpp)
+            xin = p.x[(((size_t)(b % p.src_batch) * p.C + ic) * p.S + (ti * p.p + iu)) * p.S + (tj * p.p + iv)];
+        float pv = cb;
+        for (int i = 0; i < cpp; ++i) {
+            const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xin), i));
+            pv = fmaf(cw[i], xv, pv);
+        }
+        if (lane >= p.pd) pv = 0.f;
+        const float inv_pd = 1.0f / (float)p.pd;
+        const float mean1 = wave_sum(pv) * inv_pd;
+        const float dv = lane < p.pd ? pv - mean1 : 0.f;
+        const float rstd1 = 1.0f / sqrtf(wave_sum(dv * dv) * inv_pd + kLnEps);
+        const float pn = dv * rstd1 * g1 + b1;                   // 0 for lanes >= pd
 
-    // Linear pd -> d: lane owns features {2l, 2l+1} + 128 j
-    float2 e[NJ];
+        float2 e[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) e[j] = *reinterpret_cast<const float2*>(p.lin_b + j * 128 + 2 * lane);
-#pragma unroll 4
-    for (int o = 0; o < p.pd; ++o) {
-        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pn), o));
-        const float* wrow = p.lin_wt + (size_t)o * p.d + 2 * lane;
+        for (int j = 0; j < NJ; ++j) e[j] = *reinterpret_cast<const float2*>(p.lin_b + j * 128 + 2 * lane);
+        for (int o = 0; o < p.pd; ++o) {
+            const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pn), o));
+            const float* wrow = wt + o * d + 2 * lane;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float2 w = *reinterpret_cast<const float2*>(wrow + j * 128);
+                e[j].x = fmaf(a, w.x, e[j].x); e[j].y = fmaf(a, w.y, e[j].y);
+            }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) s += e[j].x + e[j].y;
+        const float mean2 = wave_sum(s) / (float)d;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { e[j].x -= mean2; e[j].y -= mean2; q += e[j].x * e[j].x + e[j].y * e[j].y; }
+        const float rstd2 = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const float2 w = *reinterpret_cast<const float2*>(wrow + j * 128);
-            e[j].x = fmaf(a, w.x, e[j].x); e[j].y = fmaf(a, w.y, e[j].y);
+            const int n = j * 128 + 2 * lane;
+            const float2 g = *reinterpret_cast<const float2*>(p.ln2_w + n);
+            const float2 bb = *reinterpret_cast<const float2*>(p.ln2_b + n);
+            const float2 pe = *reinterpret_cast<const float2*>(p.pos + (size_t)t * d + n);
+            float2 o;
+            o.x = e[j].x * rstd2 * g.x + bb.x + pe.x;
+            o.y = e[j].y * rstd2 * g.y + bb.y + pe.y;
+            *reinterpret_cast<float2*>(p.tok + (size_t)row * d + n) = o;
         }
-    }
-    // LN over d
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) s += e[j].x + e[j].y;
-    const float mean2 = wave_sum(s) / (float)p.d;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) { e[j].x -= mean2; e[j].y -= mean2; q += e[j].x * e[j].x + e[j].y * e[j].y; }
-    const float rstd2 = 1.0f / sqrtf(wave_sum(q) / (float)p.d + kLnEps);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = j * 128 + 2 * lane;
-        const float2 g = *reinterpret_cast<const float2*>(p.ln2_w + n);
-        const float2 bb = *reinterpret_cast<const float2*>(p.ln2_b + n);
-        const float2 pe = *reinterpret_cast<const float2*>(p.pos + (size_t)t * p.d + n);
-        float2 o;
-        o.x = e[j].x * rstd2 * g.x + bb.x + pe.x;
-        o.y = e[j].y * rstd2 * g.y + bb.y + pe.y;
-        *reinterpret_cast<float2*>(p.tok + (size_t)row * p.d + n) = o;
     }
 }
 
@@ -305,17 +312,23 @@ __global__ __launch_bounds__(256) void tail_kernel(TailParams p, int rows_per_bl
 #pragma unroll
         for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const float2*>(p.tok + (size_t)row * d + j * 128 + 2 * lane);
         float mine = 0.f;
-#pragma unroll 4
-        for (int o = 0; o < p.pd; ++o) {
-            float part = 0.f;
-            const float* wrow = w + o * d + 2 * lane;
+        for (int o4 = 0; o4 < p.pd; o4 += 4) {              // four independent dot-product / reduction chains
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const float2 ww = *reinterpret_cast<const float2*>(wrow + j * 128);
-                part = fmaf(v[j].x, ww.x, fmaf(v[j].y, ww.y, part));
+            for (int u = 0; u < 4; ++u) {
+                const int o = o4 + u < p.pd ? o4 + u : p.pd - 1;
+                const float* wrow = w + o * d + 2 * lane;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float2 ww = *reinterpret_cast<const float2*>(wrow + j * 128);
+                    part[u] = fmaf(v[j].x, ww.x, fmaf(v[j].y, ww.y, part[u]));
+                }
             }
-            const float tot = wave_sum(part);
-            if (lane == o) mine = tot + p.b[o];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float tot = wave_sum(part[u]);
+                if (lane == o4 + u) mine = tot + p.b[lane < p.pd ? lane : 0];
+            }
         }
         if (lane < p.pd) {
             // feature f = (c, u, v) of token (ti, tj) -> out[b, c, ti*p+u, tj*p+v]
@@ -519,7 +532,8 @@ __global__ __launch_bounds__(256) void dwconv_gelu_tiled_kernel(const bf16* __re
 
 void launch_embed(const EmbedParams& p, hipStream_t s) {
     const int rows = p.batch * p.ntok;
-    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(embed_kernel<NJ>, dim3((rows + 3) / 4), dim3(256), 0, s, p));
+    const int lds = p.pd * p.d * (int)sizeof(float);
+    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(embed_kernel<NJ>, dim3((rows + 63) / 64), dim3(256), lds, s, p));
 }
 
 void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf16* out, int M, int d,

@@ -40,10 +40,13 @@ def sharded_sample(sample_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tenso
     lo, hi = shard_bounds(B, world, rank)
     mine = sample_fn(x_T[lo:hi], labels[lo:hi]) if hi > lo else x_T.new_zeros((0,) + tuple(x_T.shape[1:]))
     mine = mine.contiguous()
+    home = mine.device
+    if dist.get_backend(group) == "gloo" and mine.is_cuda:
+        mine = mine.cpu()          # plumbing tests on a 1-GPU box only: gloo has no device collectives
     if B % world == 0:
         out = torch.empty((B,) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
         dist.all_gather_into_tensor(out, mine, group=group)       # one collective, equal shards
-        return out
+        return out.to(home)
     # ragged tail: pad shards to the largest size, gather once, then trim
     per = (B + world - 1) // world
     pad = mine.new_zeros((per,) + tuple(mine.shape[1:]))
@@ -54,7 +57,7 @@ def sharded_sample(sample_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tenso
     for r in range(world):
         l2, h2 = shard_bounds(B, world, r)
         parts.append(buf[r * per: r * per + (h2 - l2)])
-    return torch.cat(parts, dim=0)
+    return torch.cat(parts, dim=0).to(home)
 
 
 def generate_latents_sharded(gen, labels: torch.Tensor, n_iter: int = 30, num_imgs: int = 16,
