@@ -27,6 +27,8 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
 constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;   // (1/sqrt(64)) * log2(e)
 
 template <int KT, int NW>   // 32-key tiles per chunk; NW waves (32 query rows each) per workgroup
@@ -80,22 +82,21 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
             }
         }
-        // ---- stage V^T chunk through registers: 64 rows x KC keys, 16 B (8 keys) per piece
+        // K must be complete before S = K Q^T; the V^T chunk is only needed for the second MFMA, so its global
+        // loads are issued now and their latency hides behind the 32 score MFMAs and the softmax VALU work.
+        __syncthreads();
+        constexpr int PIECES = 64 * (KC / 8);
+        constexpr int PER_THREAD = PIECES / (NW * 64);
+        u32x4 vreg[PER_THREAD];
         {
             const bf16* vbase = vt + ((size_t)b * d + h * 64) * ntok + (size_t)ch * KC;
-            constexpr int PIECES = 64 * (KC / 8);
-            constexpr int PER_THREAD = PIECES / (NW * 64);
 #pragma unroll
             for (int it = 0; it < PER_THREAD; ++it) {
                 const int pidx = it * (NW * 64) + threadIdx.x;
                 const int c = pidx / (KC / 8), kc8 = pidx % (KC / 8);
-                const uint4 val = *reinterpret_cast<const uint4*>(vbase + (size_t)c * ntok + kc8 * 8);
-                uint2* dst = reinterpret_cast<uint2*>(Vs + c * VSTRIDE + kc8 * 16);
-                dst[0] = make_uint2(val.x, val.y);
-                dst[1] = make_uint2(val.z, val.w);
+                vreg[it] = *reinterpret_cast<const u32x4*>(vbase + (size_t)c * ntok + kc8 * 8);
             }
         }
-        __syncthreads();
 
         // ---- S^T = K Q^T : KT tiles of [32 keys x 32 queries]
         f32x16 st[KT];
@@ -130,6 +131,17 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
         }
+
+        // ---- V^T chunk: registers -> LDS (padded pitch), visible to every wave after the barrier
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            const int pidx = it * (NW * 64) + threadIdx.x;
+            const int c = pidx / (KC / 8), kc8 = pidx % (KC / 8);
+            uint2* dst = reinterpret_cast<uint2*>(Vs + c * VSTRIDE + kc8 * 16);
+            dst[0] = make_uint2(vreg[it][0], vreg[it][1]);
+            dst[1] = make_uint2(vreg[it][2], vreg[it][3]);
+        }
+        __syncthreads();
 
         // ---- P = exp2(s' - m), O^T += V^T P^T
 #pragma unroll

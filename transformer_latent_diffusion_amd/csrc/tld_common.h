@@ -82,6 +82,7 @@ struct GemmParams {
     int ntok, d;                  // EPI_QKV
     const float* bias;            // EPI_BIAS_*
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
+    unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop
 };
 

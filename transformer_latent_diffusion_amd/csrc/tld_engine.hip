@@ -588,6 +588,12 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     g.dbg_no_dma = (getenv("TLD_GEMM_DBG") && atoi(getenv("TLD_GEMM_DBG")) == 2) ? 1 : 0;
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+    unsigned long long* trace = nullptr;
+    if (getenv("TLD_GEMM_TRACE")) {
+        HIP_TRY(hipMalloc(&trace, 8 * 16 * 6 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(trace, 0, 8 * 16 * 6 * sizeof(unsigned long long)));
+        g.trace = trace;
+    }
     auto run = [&]() { launch_gemm(g, epilogue, nullptr); };
     for (int i = 0; i < 3; ++i) run();
     HIP_TRY(hipEventRecord(a, nullptr));
@@ -597,6 +603,19 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, a, b));
     *avg_ms = ms / iters;
+    if (trace) {
+        std::vector<unsigned long long> h(8 * 16 * 6);
+        HIP_TRY(hipMemcpy(h.data(), trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        const unsigned long long t00 = h[0];
+        printf("# s_memtime trace, workgroup 0, first tile: per wave, per K-step: top | +vmcnt | +barrier | +grp0 | +grp3 issued | +lgkm  (cycles since wave0 step0)\n");
+        for (int w = 0; w < 8; ++w)
+            for (int k = 0; k < 12; ++k) {
+                printf("w%d k%2d:", w, k);
+                for (int sl = 0; sl < 6; ++sl) printf(" %7lld", (long long)(h[(w * 16 + k) * 6 + sl] - t00));
+                printf("\n");
+            }
+        hipFree(trace);
+    }
     hipEventDestroy(a); hipEventDestroy(b);
     hipFree(A); hipFree(W); hipFree(out); hipFree(vt); hipFree(bias); hipFree(res);
     HIP_TRY(hipGetLastError());

@@ -185,9 +185,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             // and the last MFMA group of a step is executed AFTER the next step's barrier, so the pipe has
             // register-resident work while the first fragments of the new tile are read from LDS.
             constexpr int NP = G::A_PIECES + G::B_PIECES;           // pieces per wave per K-step
+            // optional cycle trace (block 0, first 16 K-steps of its first tile): 6 stamps per step per wave
+            auto stamp = [&](int k, int slot) {
+                if (p.trace && blockIdx.x == 0 && it == 0 && k < 16 && lane == 0)
+                    p.trace[(wid * 16 + k) * 6 + slot] = __builtin_amdgcn_s_memtime();
+            };
             for (int k = 0; k < nk; ++k, ++g) {
+                stamp(k, 0);
                 wait_vmcnt<0>();                   // own DMA pieces of step g landed (and earlier epilogue stores)
+                stamp(k, 1);
                 __builtin_amdgcn_s_barrier();      // everybody's; stage (g+1)&1 (operands or epilogue scratch) is idle
+                stamp(k, 2);
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
                 const bool more = (k + 1 < nk) || has_next;
@@ -205,6 +213,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 load_frags(st, 0, a0, b0);
                 pieces(0, (NP + 3) / 4);
                 if (k > 0) mma(a1, b1);            // deferred: k-slice 3 of the previous step (fragments already in registers)
+                stamp(k, 3);
                 load_frags(st, 1, a1, b1);
                 pieces((NP + 3) / 4, (NP + 1) / 2);
                 mma(a0, b0);
@@ -214,7 +223,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 load_frags(st, 3, a1, b1);
                 pieces((3 * NP + 3) / 4, NP);
                 mma(a0, b0);
+                stamp(k, 4);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // k-slice 3 fragments are in registers before the stage is released
+                stamp(k, 5);
             }
             mma(a1, b1);                           // k-slice 3 of the tile's last step
         };
