@@ -205,6 +205,27 @@ def test_seed_path_and_api_smoke():
     assert torch.equal(lat, lat2)                         # same seed -> same device-generator noise
 
 
+def test_edge_batches_and_engine_growth():
+    """empty batch, batch 1, odd batches, and a batch larger than the engine was built for (engine is rebuilt)."""
+    from transformer_latent_diffusion_amd import Denoiser, DenoiserConfig, DiffusionGenerator
+    cfg = DenoiserConfig(n_channels=4)
+    m = Denoiser(**asdict(cfg)).to(_dev())
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(13, 4, 16, 16, generator=g).to(_dev())
+    s = (torch.rand(13, 1, generator=g) * 0.9 + 0.05).to(_dev())
+    lab = torch.randn(13, 768, generator=g).to(_dev())
+    assert m(x[:0], s[:0], lab[:0]).shape == (0, 4, 16, 16)
+    o13 = m(x, s, lab)                                  # first call sizes the engine for 13
+    o1 = m(x[:1], s[:1], lab[:1])
+    assert torch.equal(o1[0], o13[0])
+    big = m(x.repeat(3, 1, 1, 1), s.repeat(3, 1), lab.repeat(3, 1))     # 39 > capacity -> rebuild
+    assert torch.equal(big[:13], o13) and torch.equal(big[26:], o13)
+    gen = DiffusionGenerator(m, None, _dev(), torch.float32)
+    assert gen.generate_latents(lab[:0].cpu(), num_imgs=0, seeds=x[:0].cpu(), n_iter=5, img_size=16).shape == (0, 4, 16, 16)
+    with pytest.raises(RuntimeError):
+        m(x[:, :3], s, lab)                             # wrong channel count
+
+
 def test_bf16_io_matches_fp32_io():
     g = load_golden("g1_tiny32_forward.npz")
     cfg, sd, m = _engine(g)

@@ -169,6 +169,8 @@ class Denoiser:
         if x.dim() != 4 or x.shape[1] != self.n_channels or x.shape[2] != self.image_size or x.shape[3] != self.image_size:
             raise RuntimeError(f"expected x of shape [B,{self.n_channels},{self.image_size},{self.image_size}], got {tuple(x.shape)}")
         B = x.shape[0]
+        if B == 0:                                   # empty batch: nothing to enqueue (nn.Module would return an empty tensor)
+            return torch.empty_like(x)
         if noise_level.numel() != B or label.shape != (B, self.text_emb_size):
             raise RuntimeError(f"noise_level {tuple(noise_level.shape)} / label {tuple(label.shape)} do not match batch {B}")
         dt = x.dtype
@@ -194,6 +196,9 @@ class Denoiser:
         coeffs = schedule.step_coefficients(...).  Returns fp32 latent [B,C,S,S] (+ traces)."""
         dev = self._resolve_device(x_T)
         B = x_T.shape[0]
+        if B == 0:
+            z = torch.empty_like(x_T, dtype=torch.float32)
+            return (z, None, None) if trace else z
         h = self._ensure_engine(2 * B, dev)
         xT = x_T.to(device=dev, dtype=torch.float32).contiguous()
         lab = labels.to(device=dev, dtype=torch.float32).contiguous()
