@@ -70,6 +70,8 @@ enum GemmEpilogue {
     EPI_QKV = 1,         // q,k -> bf16 [M,2d] ; v -> bf16 transposed per (sample, head): [B,H,64,Ntok]
     EPI_BIAS_BF16 = 2,   // bf16(C + bias[n]) -> [M,N]           (MLP up projection)
     EPI_BIAS_RESID = 3,  // x[m,n] += C + bias[n] (resid_t)      (MLP down projection)
+    EPI_UP_DWCONV = 4,   // bf16(C + bias) -> depthwise 3x3 + bias + GELU over the tile's 16x16 image -> [M,N]
+                         // (MLP up projection fused with the depthwise conv; needs ntok == 256, BN == 256)
 };
 
 struct GemmParams {
@@ -81,6 +83,8 @@ struct GemmParams {
     bf16* vt;                     // EPI_QKV
     int ntok, d;                  // EPI_QKV
     const float* bias;            // EPI_BIAS_*
+    const float* dw_w9c;          // EPI_UP_DWCONV: depthwise weights [9][N]
+    const float* dw_b;            // EPI_UP_DWCONV: depthwise bias [N]
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
     unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop

@@ -66,6 +66,7 @@ struct tld_engine {
     tld_config cfg{};
     int d = 0, L = 0, H = 0, ntok = 0, grid = 0, pd = 0, hid = 0, img = 0, ne = 0, text = 0;
     bool finalized = false;
+    bool fuse_dwconv = true;            // TLD_FUSE_DWCONV=0 selects the two-kernel path (A/B testing)
     std::map<std::string, HostTensor> host;
     std::vector<void*> allocs;
     int64_t weight_bytes = 0;
@@ -270,16 +271,27 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             launch_cross_row(cp, s);
         }
         if (l == 0) if (int rc = capture(e, "blk0_ca", e->x, (size_t)M * d, s)) return rc;
-        {   // hid1 = xn Wup^T + b
+        // 256 px (16x16 tokens): one GEMM tile row-block is one image, so the depthwise conv + GELU run inside the
+        // up-projection's epilogue and the pre-conv hidden never reaches HBM.  Other grids: separate kernels.
+        const bool fuse_dw = e->fuse_dwconv && e->grid == 16 && e->hid % 256 == 0;
+        if (fuse_dw) {
             ProfScope ps(e, KC_GEMM_UP, s);
             GemmParams g{};
             g.A = e->xn; g.lda = d; g.W = Ly.up_w; g.ldw = d; g.M = M; g.N = e->hid; g.K = d;
-            g.out_bf16 = e->hid1; g.ldo = e->hid; g.bias = Ly.up_b;
-            launch_gemm(g, EPI_BIAS_BF16, s);
-        }
-        {
-            ProfScope ps(e, KC_DWCONV, s);
-            launch_dwconv_gelu(e->hid1, e->hid2, Ly.dw_w9c, Ly.dw_b, batch, e->grid, e->hid, s);
+            g.out_bf16 = e->hid2; g.ldo = e->hid; g.bias = Ly.up_b; g.dw_w9c = Ly.dw_w9c; g.dw_b = Ly.dw_b;
+            launch_gemm(g, EPI_UP_DWCONV, s);
+        } else {
+            {   // hid1 = xn Wup^T + b
+                ProfScope ps(e, KC_GEMM_UP, s);
+                GemmParams g{};
+                g.A = e->xn; g.lda = d; g.W = Ly.up_w; g.ldw = d; g.M = M; g.N = e->hid; g.K = d;
+                g.out_bf16 = e->hid1; g.ldo = e->hid; g.bias = Ly.up_b;
+                launch_gemm(g, EPI_BIAS_BF16, s);
+            }
+            {
+                ProfScope ps(e, KC_DWCONV, s);
+                launch_dwconv_gelu(e->hid1, e->hid2, Ly.dw_w9c, Ly.dw_b, batch, e->grid, e->hid, s);
+            }
         }
         {   // x += hid2 Wdown^T + b
             ProfScope ps(e, KC_GEMM_DOWN, s);
@@ -341,6 +353,7 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     e->pd = pd; e->hid = c->mlp_multiplier * c->embed_dim; e->img = c->n_channels * c->image_size * c->image_size;
     e->ne = c->noise_embed_dims; e->text = c->text_emb_size;
     e->layers.resize(e->L);
+    if (const char* fd = getenv("TLD_FUSE_DWCONV")) e->fuse_dwconv = atoi(fd) != 0;
     *out = e;
     return TLD_OK;
 }

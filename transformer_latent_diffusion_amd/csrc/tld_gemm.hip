@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         int m0n = 0, n0n = 0;
         const bool has_next = it + 1 < my_tiles;
         if (has_next) tile_coords(it + 1, m0n, n0n);
-        bool swapped = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID);
+        bool swapped = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID || EPI == EPI_UP_DWCONV);
         if constexpr (EPI == EPI_QKV) swapped = n0 < 2 * p.d;
 
         f32x16 acc[G::TM][G::TN];
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 stamp(k, 2);
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
-                const bool more = (k + 1 < nk) || has_next;
+                const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV);
                 const int pm0 = (k + 1 < nk) ? m0 : m0n, pn0 = (k + 1 < nk) ? n0 : n0n;
                 const int pk = (k + 1 < nk) ? (k + 1) * G::BK : 0;
                 auto pieces = [&](int lo, int hi_) {
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     }
                 };
                 load_frags(st, 0, a0, b0);
-                pieces(0, (NP + 3) / 4);
                 if (k > 0) mma(a1, b1);            // deferred: k-slice 3 of the previous step (fragments already in registers)
+                pieces(0, (NP + 3) / 4);
                 stamp(k, 3);
                 load_frags(st, 1, a1, b1);
                 pieces((NP + 3) / 4, (NP + 1) / 2);
@@ -255,7 +255,92 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         } else {
             __builtin_amdgcn_s_barrier();          // all waves finished reading the last stage: reuse it as scratch
             char* ws = smem + ((g - 1) & 1) * G::STAGE_BYTES + wid * G::SCRATCH;
-            if constexpr (EPI == EPI_BIAS_RESID) {
+            if constexpr (EPI == EPI_UP_DWCONV) {
+                // The tile's 256 rows are the 16x16 tokens of ONE sample, so the depthwise 3x3 conv of the MLP is
+                // tile-local: hidden = bf16(acc + bias) goes to LDS as [256 tokens][256 channels] (128 KB: both
+                // stages -- this epilogue therefore gives up the cross-tile prefetch), then every thread slides a
+                // 3x3 fp32 window along an image row for one channel quad, applies bias + exact GELU and stores 8 B.
+                // The pre-conv hidden tensor never travels to HBM (a 200 MB write + read per layer) and the separate
+                // kernel disappears.  16-B chunks of a token row are XOR-swizzled with (token & 31).
+                static_assert(BN == 256, "fused depthwise epilogue is written for 256-column tiles");
+                char* H = smem;
+#pragma unroll
+                for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const int cl = wn * 64 + j * 32 + 8 * rq + 4 * hi;               // channel inside the tile
+                            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + cl);
+                            bf16x4 pk;
+                            pk[0] = (bf16)(acc[i][j][rq * 4 + 0] + bv.x);
+                            pk[1] = (bf16)(acc[i][j][rq * 4 + 1] + bv.y);
+                            pk[2] = (bf16)(acc[i][j][rq * 4 + 2] + bv.z);
+                            pk[3] = (bf16)(acc[i][j][rq * 4 + 3] + bv.w);
+                            const int tok = wm * G::WROWS + i * 32 + l31;
+                            *reinterpret_cast<bf16x4*>(H + tok * 512 + ((((cl >> 3) ^ (tok & 31)) << 4) | ((cl & 7) << 1))) = pk;
+                        }
+                __builtin_amdgcn_s_barrier();
+                {
+                    const int cq = threadIdx.x & 63;                     // channel quad (64 per token row)
+                    const int c0 = n0 + cq * 4;
+                    float4 w[9];
+#pragma unroll
+                    for (int k9 = 0; k9 < 9; ++k9) w[k9] = *reinterpret_cast<const float4*>(p.dw_w9c + (size_t)k9 * p.N + c0);
+                    const float4 bs = *reinterpret_cast<const float4*>(p.dw_b + c0);
+#pragma unroll 1
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int irow = (threadIdx.x >> 6) + rr * 8;    // image row 0..15
+                        const bool up_ok = irow > 0, dn_ok = irow < 15;
+                        auto col = [&](int jj, float4 (&c)[3]) {
+                            const bool jok = jj >= 0 && jj < 16;
+#pragma unroll
+                            for (int du = 0; du < 3; ++du) {
+                                const bool ok = jok && (du == 1 || (du == 0 ? up_ok : dn_ok));
+                                if (ok) {
+                                    const int tok = (irow + du - 1) * 16 + jj;
+                                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(
+                                        H + tok * 512 + ((((cq >> 1) ^ (tok & 31)) << 4) | ((cq & 1) << 3)));
+                                    c[du] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+                                } else {
+                                    c[du] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                }
+                            }
+                        };
+                        bf16* dst = p.out_bf16 + ((size_t)m0 + irow * 16) * p.ldo + c0;
+                        auto emit = [&](const float4 (&L)[3], const float4 (&Mc)[3], const float4 (&R)[3], int jj) {
+                            float4 part[3];
+#pragma unroll
+                            for (int du = 0; du < 3; ++du) {
+                                const float4 w0 = w[du * 3 + 0], w1 = w[du * 3 + 1], w2 = w[du * 3 + 2];
+                                part[du].x = fmaf(w2.x, R[du].x, fmaf(w1.x, Mc[du].x, w0.x * L[du].x));
+                                part[du].y = fmaf(w2.y, R[du].y, fmaf(w1.y, Mc[du].y, w0.y * L[du].y));
+                                part[du].z = fmaf(w2.z, R[du].z, fmaf(w1.z, Mc[du].z, w0.z * L[du].z));
+                                part[du].w = fmaf(w2.w, R[du].w, fmaf(w1.w, Mc[du].w, w0.w * L[du].w));
+                            }
+                            bf16x4 o;
+                            o[0] = (bf16)gelu_erf_fast((part[0].x + part[1].x) + (part[2].x + bs.x));
+                            o[1] = (bf16)gelu_erf_fast((part[0].y + part[1].y) + (part[2].y + bs.y));
+                            o[2] = (bf16)gelu_erf_fast((part[0].z + part[1].z) + (part[2].z + bs.z));
+                            o[3] = (bf16)gelu_erf_fast((part[0].w + part[1].w) + (part[2].w + bs.w));
+                            if (m0 + irow * 16 + jj < p.M) *reinterpret_cast<bf16x4*>(dst + (size_t)jj * p.ldo) = o;
+                        };
+                        float4 c0v[3], c1v[3], c2v[3];
+                        col(-1, c0v);
+                        col(0, c1v);
+                        int jj = 0;
+                        for (; jj + 3 <= 16; jj += 3) {
+                            col(jj + 1, c2v); emit(c0v, c1v, c2v, jj);
+                            col(jj + 2, c0v); emit(c1v, c2v, c0v, jj + 1);
+                            col(jj + 3, c1v); emit(c2v, c0v, c1v, jj + 2);
+                        }
+                        col(jj + 1, c2v); emit(c0v, c1v, c2v, jj);       // jj == 15
+                    }
+                }
+                // the ring restarts for the next tile: its first K-step could not be prefetched (LDS was the image)
+                __builtin_amdgcn_s_barrier();
+                if (has_next) issue(m0n, n0n, 0, g);
+            } else if constexpr (EPI == EPI_BIAS_RESID) {
                 constexpr int P = 32 * 4 + 16;      // one 32x32 fp32 tile, padded pitch
 #pragma unroll
                 for (int i = 0; i < G::TM; ++i)
@@ -387,6 +472,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
             case EPI_QKV: TLD_L256P(EPI_QKV); break;
             case EPI_BIAS_BF16: TLD_L256P(EPI_BIAS_BF16); break;
             case EPI_BIAS_RESID: TLD_L256P(EPI_BIAS_RESID); break;
+            case EPI_UP_DWCONV: if constexpr (BN == 256) { TLD_L256P(EPI_UP_DWCONV); } break;
             default: break;
         }
     }
@@ -405,6 +491,7 @@ void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s) {
     int bn = narrow ? 128 : 256;
     if (narrow && epilogue == EPI_BIAS_RESID && p.N % 192 == 0 && (ntm * (p.N / 192)) % 256 == 0) bn = 192;
     if (force) bn = atoi(force);
+    if (epilogue == EPI_UP_DWCONV) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
     if (bn == 192 && (epilogue != EPI_BIAS_RESID || p.N % 192)) bn = 128;
     if (bn == 192) launch256p<192>(p, epilogue, s);
     else if (bn == 128) launch256p<128>(p, epilogue, s);
