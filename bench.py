@@ -48,9 +48,9 @@ def pmc_traffic(cls):
     path = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
     if not os.path.exists(path):
         return None, None
-    epi = {"gemm_qkv": ", 1>", "gemm_up": ", 2>", "gemm_down": ", 3>"}[cls]
+    epis = {"gemm_qkv": (", 1>",), "gemm_up": (", 4>", ", 2>"), "gemm_down": (", 3>",)}[cls]   # 4 = up fused with dwconv+GELU
     for name, v in json.load(open(path)).items():
-        if "gemm256_kernel" in name and epi in name:
+        if "gemm256p_kernel" in name and any(e in name for e in epis):
             return v["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)"
     return None, None
 
@@ -198,7 +198,7 @@ def main():
             tot_t = sum(prof[c][0] for c in prof) / 1e3
             traffic, traffic_src = pmc_traffic(dom)
             line["roofline"] = {
-                "bound": "mfma", "kernel": f"gemm256_kernel<{dom}>", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                "bound": "mfma", "kernel": f"gemm256p_kernel<{dom}>", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": ms / max(n, 1), "launches": n,
                 "flops_per_launch": gemm_flops(dom, M, cfg.embed_dim),

@@ -1,8 +1,9 @@
 """GPU parity tests: the HIP engine (through the C ABI) vs the reference's golden vectors and the CPU oracle.
 
-Tolerances (the engine multiplies in bf16 with fp32 accumulation, keeps the
-residual stream, LayerNorm statistics, softmax and the whole conditioning path in fp32):
-  fp32-only stages (conditioning tokens, patch embedding): max-abs <= 2e-4
+Tolerances (the engine multiplies in bf16 with fp32 accumulation, stores the residual
+stream in bf16 like the reference's bf16 mode, and keeps LayerNorm statistics, softmax, residual adds and the
+whole conditioning path in fp32):
+  fp32-only stages (conditioning tokens): max-abs <= 2e-4
   one forward vs the fp32 reference: rel-rms <= 2e-2
   multi-step CFG trajectory end latent: rel-rms <= 6e-2
 """
@@ -68,8 +69,10 @@ def test_g1_stages_tiny32():
     # engine row order: B noise tokens then B label tokens; golden: [B, 2, d]
     assert max_abs(y[:B], g["cond_y"][:, 0]) <= 2e-4
     assert max_abs(y[B:], g["cond_y"][:, 1]) <= 2e-4
+    # patch embedding is computed in fp32 and stored once into the bf16 residual stream: half-ulp = 2^-9 relative
     t0 = m.read_stage("tokens0", (B, N, d))
-    assert max_abs(t0, g["tokens0"]) <= 2e-4
+    assert max_abs(t0, g["tokens0"]) <= 2.0 ** -8 * float(np.abs(g["tokens0"]).max())
+    assert rel_rms(t0, g["tokens0"]) <= 3e-3
     for k, tol in (("blk0_sa", 1e-2), ("blk0_ca", 1e-2), ("blk0_mlp", 1e-2), ("tokens_final", FWD_TOL)):
         st = m.read_stage(k, (B, N, d))
         assert rel_rms(st, g[k]) <= tol, (k, rel_rms(st, g[k]))

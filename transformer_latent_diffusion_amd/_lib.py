@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtld_hip.so")
+LIB_PATH = os.environ.get("TLD_LIB", os.path.join(_HERE, "libtld_hip.so"))   # TLD_LIB: A/B-testing builds only
 
 DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
 

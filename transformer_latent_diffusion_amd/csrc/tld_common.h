@@ -13,9 +13,16 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
-// Residual stream dtype.  fp32 keeps the 36 residual adds of a forward exact to fp32 rounding;
-// GEMM/attention operands are bf16 regardless.
+// Residual stream dtype: bf16, as in the reference's own bf16 mode (x never leaves bf16 there either).  All
+// statistics, softmax and residual ADDS are computed in fp32 and rounded once on store.  Measured vs the fp32
+// reference: forward rel-rms 5-7e-3, 35-step CFG-6 trajectory 1.4e-2 (tolerances 2e-2 / 6e-2; the reference's
+// own bf16 path is at 0.8-1.0e-2 per forward).  -DTLD_RESID_FP32 keeps x in fp32 (2.7e-3 / 4.6e-3, ~4 % slower).
+#ifdef TLD_RESID_FP32
 typedef float resid_t;
+#else
+#define TLD_RESID_BF16 1
+typedef __bf16 resid_t;
+#endif
 
 constexpr int kWave = 64;
 constexpr int kHeadDim = 64;
@@ -61,6 +68,39 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) {
     return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ float2 rs_load2(const resid_t* p) {
+#ifdef TLD_RESID_BF16
+    const bf16x2 v = *reinterpret_cast<const bf16x2*>(p);
+    return make_float2((float)v[0], (float)v[1]);
+#else
+    return *reinterpret_cast<const float2*>(p);
+#endif
+}
+__device__ __forceinline__ void rs_store2(resid_t* p, float2 v) {
+#ifdef TLD_RESID_BF16
+    bf16x2 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y;
+    *reinterpret_cast<bf16x2*>(p) = o;
+#else
+    *reinterpret_cast<float2*>(p) = v;
+#endif
+}
+__device__ __forceinline__ float4 rs_load4(const resid_t* p) {
+#ifdef TLD_RESID_BF16
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void rs_store4(resid_t* p, float4 v) {
+#ifdef TLD_RESID_BF16
+    bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+    *reinterpret_cast<bf16x4*>(p) = o;
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
 }
 
 // ---- launch descriptors ------------------------------------------------------------------------

@@ -179,14 +179,14 @@ struct ProfScope {
     }
 };
 
-int capture(tld_engine* e, const char* name, const float* src, size_t count, hipStream_t s) {
+int capture(tld_engine* e, const char* name, const resid_t* src, size_t count, hipStream_t s) {
     if (!e->debug) return TLD_OK;
     float*& buf = e->stages[name];
     if (!buf) {
         const size_t cap = (size_t)std::max(e->cfg.max_batch * e->ntok, 4 * e->cfg.max_batch + 1024) * e->d;
         if (int rc = dev_alloc(e, &buf, cap)) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(buf, src, count * sizeof(float), hipMemcpyDeviceToDevice, s));
+    launch_cast_to_f32(src, sizeof(resid_t) == 2 ? TLD_DTYPE_BF16 : TLD_DTYPE_F32, buf, (int64_t)count, s);
     return TLD_OK;
 }
 
@@ -586,7 +586,7 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     if (!avg_ms || M <= 0 || N <= 0 || K <= 0 || K % 64 || iters <= 0) return fail(TLD_ERR_INVALID, "bad argument");
     if (epilogue == EPI_QKV && (N % 3 || ntok <= 0 || M % ntok)) return fail(TLD_ERR_INVALID, "QKV epilogue needs N = 3d, M %% ntok == 0");
     bf16 *A = nullptr, *W = nullptr, *out = nullptr, *vt = nullptr;
-    float *bias = nullptr, *res = nullptr;
+    float *bias = nullptr, *res = nullptr;   // res doubles as fp32 C and as the residual buffer (sized for fp32)
     HIP_TRY(hipMalloc(&A, (size_t)M * K * 2)); HIP_TRY(hipMalloc(&W, (size_t)N * K * 2));
     HIP_TRY(hipMalloc(&out, (size_t)M * N * 2)); HIP_TRY(hipMalloc(&vt, (size_t)M * N * 2));
     HIP_TRY(hipMalloc(&bias, (size_t)N * 4)); HIP_TRY(hipMalloc(&res, (size_t)M * N * 4));
@@ -597,7 +597,7 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     GemmParams g{};
     g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;
     g.c_f32 = res; g.ldc = N; g.out_bf16 = out; g.ldo = epilogue == EPI_QKV ? 2 * (N / 3) : N; g.vt = vt;
-    g.ntok = ntok > 0 ? ntok : 1; g.d = N / 3; g.bias = bias; g.resid = res; g.ldr = N;
+    g.ntok = ntok > 0 ? ntok : 1; g.d = N / 3; g.bias = bias; g.resid = reinterpret_cast<resid_t*>(res); g.ldr = N;
     g.dbg_no_dma = (getenv("TLD_GEMM_DBG") && atoi(getenv("TLD_GEMM_DBG")) == 2) ? 1 : 0;
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));

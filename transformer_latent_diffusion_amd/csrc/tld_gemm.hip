@@ -363,10 +363,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             const float4 v = *reinterpret_cast<const float4*>(ws + rl * P + ch * 16);
                             const int row = row0 + i * 32 + rl, col = col0 + j * 32 + ch * 4;
                             if (row < p.M && col < p.N) {
-                                float4* px = reinterpret_cast<float4*>(p.resid + (size_t)row * p.ldr + col);
-                                float4 o = *px;
+                                resid_t* px = p.resid + (size_t)row * p.ldr + col;
+                                float4 o = rs_load4(px);
                                 o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-                                *px = o;
+                                rs_store4(px, o);
                             }
                         }
                     }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
             float2 o;
             o.x = e[j].x * rstd2 * g.x + bb.x + pe.x;
             o.y = e[j].y * rstd2 * g.y + bb.y + pe.y;
-            *reinterpret_cast<float2*>(p.tok + (size_t)row * d + n) = o;
+            rs_store2(p.tok + (size_t)row * d + n, o);
         }
     }
 }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const resid_t* __re
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        v[j] = *reinterpret_cast<const float2*>(x + (size_t)row * d + j * 128 + 2 * lane);
+        v[j] = rs_load2(x + (size_t)row * d + j * 128 + 2 * lane);
         s += v[j].x + v[j].y;
     }
     const float mean = wave_sum(s) / (float)d;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = j * 128 + 2 * lane;
-            xv[j] = *reinterpret_cast<const float2*>(p.x + row * d + n);
+            xv[j] = rs_load2(p.x + row * d + n);
             av[j] = *reinterpret_cast<const bf16x2*>(p.att + row * d + n);
         }
     };
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
             for (int u = 0; u < 2; ++u) {
                 v[u][j].x += fmaf(plab[u][j], dd.x, a.x);
                 v[u][j].y += fmaf(plab[u][j], dd.y, a.y);
-                *reinterpret_cast<float2*>(p.x + (row + u) * d + n) = v[u][j];
+                rs_store2(p.x + (row + u) * d + n, v[u][j]);
                 s3[u] += v[u][j].x + v[u][j].y;
             }
         }
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailParams p, int rows_per_bl
         if (row >= total) return;
         float2 v[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) v[j] = *reinterpret_cast<const float2*>(p.tok + (size_t)row * d + j * 128 + 2 * lane);
+        for (int j = 0; j < NJ; ++j) v[j] = rs_load2(p.tok + (size_t)row * d + j * 128 + 2 * lane);
         float mine = 0.f;
         for (int o4 = 0; o4 < p.pd; o4 += 4) {              // four independent dot-product / reduction chains
             float part[4] = {0.f, 0.f, 0.f, 0.f};
