@@ -319,10 +319,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                 part[du].w = fmaf(w2.w, R[du].w, fmaf(w1.w, Mc[du].w, w0.w * L[du].w));
                             }
                             bf16x4 o;
-                            o[0] = (bf16)gelu_erf_fast((part[0].x + part[1].x) + (part[2].x + bs.x));
-                            o[1] = (bf16)gelu_erf_fast((part[0].y + part[1].y) + (part[2].y + bs.y));
-                            o[2] = (bf16)gelu_erf_fast((part[0].z + part[1].z) + (part[2].z + bs.z));
-                            o[3] = (bf16)gelu_erf_fast((part[0].w + part[1].w) + (part[2].w + bs.w));
+                            o[0] = (bf16)TLD_DW_GELU((part[0].x + part[1].x) + (part[2].x + bs.x));
+                            o[1] = (bf16)TLD_DW_GELU((part[0].y + part[1].y) + (part[2].y + bs.y));
+                            o[2] = (bf16)TLD_DW_GELU((part[0].z + part[1].z) + (part[2].z + bs.z));
+                            o[3] = (bf16)TLD_DW_GELU((part[0].w + part[1].w) + (part[2].w + bs.w));
                             if (m0 + irow * 16 + jj < p.M) *reinterpret_cast<bf16x4*>(dst + (size_t)jj * p.ldo) = o;
                         };
                         float4 c0v[3], c1v[3], c2v[3];

@@ -426,8 +426,8 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const bf16* __restrict
             const float az = (part[0].z + part[1].z) + (part[2].z + bs.z);
             const float aw = (part[0].w + part[1].w) + (part[2].w + bs.w);
             bf16x4 o;
-            o[0] = (bf16)gelu_erf_fast(ax); o[1] = (bf16)gelu_erf_fast(ay);
-            o[2] = (bf16)gelu_erf_fast(az); o[3] = (bf16)gelu_erf_fast(aw);
+            o[0] = (bf16)TLD_DW_GELU(ax); o[1] = (bf16)TLD_DW_GELU(ay);
+            o[2] = (bf16)TLD_DW_GELU(az); o[3] = (bf16)TLD_DW_GELU(aw);
             *reinterpret_cast<bf16x4*>(dst + (size_t)j * C) = o;
         };
         // the window rotates through three named column buffers, so no register copies are needed
@@ -505,10 +505,10 @@ __global__ __launch_bounds__(256) void dwconv_gelu_tiled_kernel(const bf16* __re
             part[du].w = fmaf(w2.w, cR[du].w, fmaf(w1.w, cM[du].w, w0.w * cL[du].w));
         }
         bf16x4 o;
-        o[0] = (bf16)gelu_erf_fast((part[0].x + part[1].x) + (part[2].x + bs.x));
-        o[1] = (bf16)gelu_erf_fast((part[0].y + part[1].y) + (part[2].y + bs.y));
-        o[2] = (bf16)gelu_erf_fast((part[0].z + part[1].z) + (part[2].z + bs.z));
-        o[3] = (bf16)gelu_erf_fast((part[0].w + part[1].w) + (part[2].w + bs.w));
+        o[0] = (bf16)TLD_DW_GELU((part[0].x + part[1].x) + (part[2].x + bs.x));
+        o[1] = (bf16)TLD_DW_GELU((part[0].y + part[1].y) + (part[2].y + bs.y));
+        o[2] = (bf16)TLD_DW_GELU((part[0].z + part[1].z) + (part[2].z + bs.z));
+        o[3] = (bf16)TLD_DW_GELU((part[0].w + part[1].w) + (part[2].w + bs.w));
         *reinterpret_cast<bf16x4*>(out + ((size_t)b * g * g + (size_t)gi * g + gj) * C + c0) = o;
 #pragma unroll
         for (int du = 0; du < 3; ++du) { cL[du] = cM[du]; cM[du] = cR[du]; }
