@@ -72,6 +72,39 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
 // (A transcendental-free degree-9 polynomial erf was measured ~4 % SLOWER end to end: its 10-deep dependent FMA
 // chain is latency-bound at the 2 waves/SIMD of the fused GEMM epilogue.)
 
+__device__ __forceinline__ float2 rs_load2(const resid_t* p) {
+#ifdef TLD_RESID_BF16
+    const bf16x2 v = *reinterpret_cast<const bf16x2*>(p);
+    return make_float2((float)v[0], (float)v[1]);
+#else
+    return *reinterpret_cast<const float2*>(p);
+#endif
+}
+__device__ __forceinline__ void rs_store2(resid_t* p, float2 v) {
+#ifdef TLD_RESID_BF16
+    bf16x2 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y;
+    *reinterpret_cast<bf16x2*>(p) = o;
+#else
+    *reinterpret_cast<float2*>(p) = v;
+#endif
+}
+__device__ __forceinline__ float4 rs_load4(const resid_t* p) {
+#ifdef TLD_RESID_BF16
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void rs_store4(resid_t* p, float4 v) {
+#ifdef TLD_RESID_BF16
+    bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
+    *reinterpret_cast<bf16x4*>(p) = o;
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 #ifndef TLD_DW_GELU
 #define TLD_DW_GELU gelu_erf_fast
 #endif
