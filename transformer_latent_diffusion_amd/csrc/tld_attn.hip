@@ -19,6 +19,7 @@
 // fragment is gathered with the same permutation, so no cross-lane shuffle of P is needed.
 // With more than one chunk (ntok > 256) the usual online-softmax rescale is applied per chunk.
 #include "tld_common.h"
+#include <cstdlib>
 
 namespace tld {
 
@@ -185,6 +186,147 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
     }
 }
 
+// Single-chunk specialisation (ntok == 32*KT <= 256, the 256 px case): 4-wave workgroups that walk QT query
+// tiles per wave, so K / V^T are still staged once per (sample, head) but TWO workgroups share a CU (2 x 66 KB
+// LDS, 8 waves).  The two are not synchronised with each other, so one's softmax (VALU/exp bound: ~2x the MFMA
+// time of a tile) overlaps the other's MFMAs and staging -- with one 8-wave workgroup per CU every wave was in
+// the same phase.
+template <int KT, int NW, int QT>
+__global__ __launch_bounds__(NW * 64, 2) void attn1_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ vt,
+                                                        bf16* __restrict__ att, int ntok, int d) {
+    constexpr int KC = KT * 32;
+    constexpr int VSTRIDE = KC * 2 + 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + KC * 128;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int twod = 2 * d;
+    const size_t row_base = (size_t)b * ntok;
+
+    {   // K: DMA, source-side swizzle
+        const bf16* kbase = qk + row_base * twod + d + h * 64;
+        constexpr int KP = KC / 8 / NW;
+#pragma unroll
+        for (int it = 0; it < KP; ++it) {
+            const int r = (wid * KP + it) * 8 + (lane >> 3);
+            const int clog = (lane & 7) ^ ((r >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (size_t)r * twod + clog * 8),
+                                             (lptr_t)(Ks + (wid * KP + it) * 1024), 16, 0, 0);
+        }
+    }
+    __syncthreads();
+    constexpr int PIECES = 64 * (KC / 8);
+    constexpr int PER_THREAD = PIECES / (NW * 64);
+    u32x4 vreg[PER_THREAD];
+    {
+        const bf16* vbase = vt + ((size_t)b * d + h * 64) * ntok;
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            const int pidx = it * (NW * 64) + threadIdx.x;
+            const int c = pidx / (KC / 8), kc8 = pidx % (KC / 8);
+            vreg[it] = *reinterpret_cast<const u32x4*>(vbase + (size_t)c * ntok + kc8 * 8);
+        }
+    }
+#pragma unroll 1
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q0 = (wid * QT + qt) * 32;
+        bf16x8 qf[4];
+        {
+            const bf16* qp = qk + (row_base + q0 + l31) * twod + h * 64 + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+        }
+        f32x16 st[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int row = t * 32 + l31;
+                const int kc = ks * 2 + hi;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+                st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[t], 0, 0, 0);
+            }
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = mx * kScaleLog2e;
+        if (qt == 0) {
+#pragma unroll
+            for (int it = 0; it < PER_THREAD; ++it) {
+                const int pidx = it * (NW * 64) + threadIdx.x;
+                const int c = pidx / (KC / 8), kc8 = pidx % (KC / 8);
+                uint2* dst = reinterpret_cast<uint2*>(Vs + c * VSTRIDE + kc8 * 16);
+                dst[0] = make_uint2(vreg[it][0], vreg[it][1]);
+                dst[1] = make_uint2(vreg[it][2], vreg[it][3]);
+            }
+            __syncthreads();
+        }
+        f32x16 o[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+        float l_run = 0.f;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(st[t][hf * 8 + e] * kScaleLog2e - m_new);
+                    l_run += pv;
+                    pf[e] = (bf16)pv;
+                }
+                const int kb = t * 32 + hf * 16 + hi * 4;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const char* vp = Vs + (ct * 32 + l31) * VSTRIDE + kb * 2;
+                    const uint2 v0 = *reinterpret_cast<const uint2*>(vp);
+                    const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
+                    union { uint4 u; bf16x8 v; } cvt;
+                    cvt.u = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                    o[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cvt.v, pf, o[ct], 0, 0, 0);
+                }
+            }
+        }
+        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+        bf16* op = att + (row_base + q0 + l31) * d + h * 64 + 4 * hi;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (bf16)(o[ct][rq * 4 + e] * inv);
+                *reinterpret_cast<bf16x4*>(op + ct * 32 + rq * 8) = pk;
+            }
+    }
+}
+
+template <int KT, int NW, int QT>
+void launch_attn1(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
+    constexpr int KC = KT * 32;
+    const int lds = KC * 128 + 64 * (KC * 2 + 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn1_kernel<KT, NW, QT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn1_kernel<KT, NW, QT>), dim3(1, heads, batch), dim3(NW * 64), lds, s, qk, vt, att, ntok,
+                       heads * 64);
+}
+
 template <int KT, int NW>
 void launch_kt(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
     constexpr int KC = KT * 32;
@@ -206,7 +348,9 @@ void launch_attention(const bf16* qk, const bf16* vt, bf16* att, int batch, int 
     // 256-key chunks staged once per workgroup of 8 waves (256 query rows).  Measured alternative: 4-wave
     // workgroups, two per CU (staging overlapped with compute) -- 88 us vs 60 us per layer at C1, the K/V
     // chunk is then staged twice per head and the extra L2->LDS traffic costs more than the overlap buys.
-    if (ntok % 256 == 0) launch_kt<8, 8>(qk, vt, att, batch, ntok, heads, s);
+    static const bool one_wg = getenv("TLD_ATTN_8W") != nullptr;     // A/B knob: single 8-wave workgroup per CU
+    if (ntok == 256 && !one_wg) launch_attn1<8, 4, 2>(qk, vt, att, batch, ntok, heads, s);
+    else if (ntok % 256 == 0) launch_kt<8, 8>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 128) launch_kt<4, 4>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 64) launch_kt<2, 2>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 32) launch_kt<1, 1>(qk, vt, att, batch, ntok, heads, s);
