@@ -170,8 +170,10 @@ void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf1
 //   x += att (self-attention residual);  cross-attention to the 2 conditioning tokens computed from
 //   row statistics and per-sample folded query vectors;  x += cross;  xn3 = LN3(x) in bf16.
 struct CrossRowParams {
-    resid_t* x;                   // [M,d] in/out
-    const bf16* att;              // [M,d]
+    resid_t* x;                   // [M,d] out (and in, when x_in is null)
+    const resid_t* x_in;          // optional separate input stream [src_batch*ntok, d] (CFG layer-0 sharing)
+    const bf16* att;              // [M,d]  (or [src_batch*ntok, d] with x_in)
+    int src_batch;                // with x_in: model sample b reads x_in / att of sample b % src_batch
     const float* wq;              // [T, H, d]  gamma2 * (Wq_h^T k_t[h] / 8) for this layer (per token row)
     const float* bwq;             // [T, H]     sum_j beta2[j] * (Wq_h^T k_t[h] / 8)[j]
     const float* v; int v_ld;     // [T, v_ld]  cross-attention values (per token row) for this layer

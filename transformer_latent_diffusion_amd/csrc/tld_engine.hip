@@ -81,6 +81,8 @@ struct tld_engine {
 
     // activations (sized for cfg.max_batch)
     resid_t* x = nullptr;
+    resid_t* x_half = nullptr;         // patch embedding of the un-doubled batch (CFG layer-0 sharing)
+    bool share_l0 = true;              // TLD_SHARE_L0=0 disables (A/B testing)
     bf16 *xn = nullptr, *qk = nullptr, *vt = nullptr, *att = nullptr, *hid1 = nullptr, *hid2 = nullptr;
     float *io_x = nullptr, *io_sigma = nullptr, *io_label = nullptr, *io_out = nullptr;
     float *xt = nullptr, *x0_prev = nullptr, *x0_cfg = nullptr;
@@ -220,15 +222,21 @@ void cond_label_rows(tld_engine* e, int row0, int Tl, hipStream_t s) {
 }
 
 // embed -> L decoder blocks -> tail, for `batch` model samples whose latents are x_src[b % src_batch].
+// share_l0: the model batch is [x_src ; x_src] (CFG doubling), so everything before the first cross-attention --
+// patch embedding, LN1, the QKV GEMM and self-attention of block 0 -- is identical for both halves and is
+// computed for src_batch samples only; block 0's row kernel then fans it out to the 2*src_batch streams.
 int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const int* noise_row,
-             const int* label_row, float* out, hipStream_t s) {
+             const int* label_row, float* out, hipStream_t s, bool share_l0 = false) {
     const int d = e->d, M = batch * e->ntok;
+    share_l0 = share_l0 && e->share_l0 && batch == 2 * src_batch && !e->debug;
+    const int b0 = share_l0 ? src_batch : batch;            // samples processed up to block 0's attention
+    resid_t* xe = share_l0 ? e->x_half : e->x;
     {
         ProfScope ps(e, KC_EMBED, s);
         EmbedParams ep{};
         ep.x = x_src; ep.conv_w = e->conv_w; ep.conv_b = e->conv_b; ep.ln1_w = e->pln1_w; ep.ln1_b = e->pln1_b;
         ep.lin_wt = e->plin_wt; ep.lin_b = e->plin_b; ep.ln2_w = e->pln2_w; ep.ln2_b = e->pln2_b; ep.pos = e->pos;
-        ep.tok = e->x; ep.batch = batch; ep.src_batch = src_batch; ep.C = e->cfg.n_channels;
+        ep.tok = xe; ep.batch = b0; ep.src_batch = src_batch; ep.C = e->cfg.n_channels;
         ep.S = e->cfg.image_size; ep.p = e->cfg.patch_size; ep.grid = e->grid; ep.pd = e->pd; ep.d = d;
         ep.ntok = e->ntok;
         launch_embed(ep, s);
@@ -236,20 +244,22 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
     if (int rc = capture(e, "tokens0", e->x, (size_t)M * d, s)) return rc;
     for (int l = 0; l < e->L; ++l) {
         const Layer& Ly = e->layers[l];
+        const bool half = share_l0 && l == 0;
+        const int bl = half ? b0 : batch, Ml = bl * e->ntok;
         {   // xn = LN1(x)
             ProfScope ps(e, KC_LN, s);
-            launch_layernorm_bf16(e->x, Ly.n1_w, Ly.n1_b, e->xn, M, d, s);
+            launch_layernorm_bf16(half ? xe : e->x, Ly.n1_w, Ly.n1_b, e->xn, Ml, d, s);
         }
         {   // q|k, v^T = xn Wqkv^T
             ProfScope ps(e, KC_GEMM_QKV, s);
             GemmParams g{};
-            g.A = e->xn; g.lda = d; g.W = Ly.qkv_w; g.ldw = d; g.M = M; g.N = 3 * d; g.K = d;
+            g.A = e->xn; g.lda = d; g.W = Ly.qkv_w; g.ldw = d; g.M = Ml; g.N = 3 * d; g.K = d;
             g.out_bf16 = e->qk; g.ldo = 2 * d; g.vt = e->vt; g.ntok = e->ntok; g.d = d;
             launch_gemm(g, EPI_QKV, s);
         }
         {
             ProfScope ps(e, KC_ATTN, s);
-            launch_attention(e->qk, e->vt, e->att, batch, e->ntok, e->H, s);
+            launch_attention(e->qk, e->vt, e->att, bl, e->ntok, e->H, s);
         }
         if (l == 0 && e->debug && !e->stages["blk0_sa"]) {
             float* buf = nullptr;
@@ -260,6 +270,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             ProfScope ps(e, KC_CROSS, s);
             CrossRowParams cp{};
             cp.x = e->x; cp.att = e->att;
+            cp.x_in = half ? xe : nullptr; cp.src_batch = src_batch;
             cp.wq = e->c_wq + (size_t)l * e->cond_cap * e->H * d;
             cp.bwq = e->c_bwq + (size_t)l * e->cond_cap * e->H;
             cp.v = e->c_kv + (size_t)l * e->cond_cap * 2 * d + d;     // V half of each [2d] row
@@ -354,6 +365,7 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     e->ne = c->noise_embed_dims; e->text = c->text_emb_size;
     e->layers.resize(e->L);
     if (const char* fd = getenv("TLD_FUSE_DWCONV")) e->fuse_dwconv = atoi(fd) != 0;
+    if (const char* sl = getenv("TLD_SHARE_L0")) e->share_l0 = atoi(sl) != 0;
     *out = e;
     return TLD_OK;
 }
@@ -442,6 +454,7 @@ int tld_engine_finalize_weights(tld_engine* e) {
 
     const size_t B2 = (size_t)e->cfg.max_batch, M = B2 * e->ntok;
     if (int rc = dev_alloc(e, &e->x, M * d)) return rc;
+    if (int rc = dev_alloc(e, &e->x_half, (M + 1) / 2 * d)) return rc;
     if (int rc = dev_alloc(e, &e->xn, M * d)) return rc;
     if (int rc = dev_alloc(e, &e->qk, M * 2 * d)) return rc;
     if (int rc = dev_alloc(e, &e->vt, M * d)) return rc;
@@ -553,7 +566,7 @@ int tld_sample(tld_engine* e, const void* x_T, const void* labels, const float* 
     for (int i = 0; i < n_levels; ++i) {
         const bool final_step = (i == n_levels - 1);
         // pred_image: model(cat[x_t, x_t], sigma_i, [labels; 0])   (diffusion.py:94-101)
-        if (int rc = run_body(e, e->xt, B, B2, e->rows_dev + (size_t)i * B2, label_row, e->io_out, s)) return rc;
+        if (int rc = run_body(e, e->xt, B, B2, e->rows_dev + (size_t)i * B2, label_row, e->io_out, s, true)) return rc;
         ProfScope ps(e, KC_UPDATE, s);
         UpdateParams up{};
         const float* c = coeffs + (size_t)i * 6;

@@ -166,6 +166,9 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
     const bool upper = lane >= 32;
     const int rows_per_wave = rows_per_block / 4;            // even
     const size_t wrow0 = (size_t)b * p.ntok + r0 + wid * rows_per_wave;
+    // input rows: normally the same rows; with CFG layer-0 sharing the cond and uncond samples read the one copy
+    const resid_t* xin = p.x_in ? p.x_in : p.x;
+    const size_t irow0 = p.x_in ? (size_t)(b % p.src_batch) * p.ntok + r0 + wid * rows_per_wave : wrow0;
 
     // Two rows per wave at a time (independent reduction chains fill the DPP wait states), with the next
     // pair's HBM loads issued before the current pair is processed.
@@ -175,12 +178,12 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = j * 128 + 2 * lane;
-            xv[j] = rs_load2(p.x + row * d + n);
+            xv[j] = rs_load2(xin + row * d + n);
             av[j] = *reinterpret_cast<const bf16x2*>(p.att + row * d + n);
         }
     };
-    fetch(wrow0, xr[0], ar[0]);
-    fetch(wrow0 + 1, xr[1], ar[1]);
+    fetch(irow0, xr[0], ar[0]);
+    fetch(irow0 + 1, xr[1], ar[1]);
     for (int rr = 0; rr < rows_per_wave; rr += 2) {
         float2 v[2][NJ];
 #pragma unroll
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
             }
         const size_t row = wrow0 + rr;
         if (rr + 2 < rows_per_wave) {
-            fetch(row + 2, xr[0], ar[0]);
-            fetch(row + 3, xr[1], ar[1]);
+            fetch(irow0 + rr + 2, xr[0], ar[0]);
+            fetch(irow0 + rr + 3, xr[1], ar[1]);
         }
         if (p.sa_out) {
 #pragma unroll
