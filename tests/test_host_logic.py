@@ -105,3 +105,18 @@ def test_shard_bounds_cover_exactly():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing in the shipped package may import, load or execute it."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transformer_latent_diffusion_amd")
+    offenders = []
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"(from|import)\s+oracle\b|tld_oracle|libtld_oracle|oracle/", txt):
+                    offenders.append(os.path.join(dp, f))
+    assert not offenders, offenders
