@@ -47,6 +47,16 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
+// Sum within each 32-lane half of the wave (every lane ends with its half's total).
+__device__ __forceinline__ float half_sum(float v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp, one v_exp, six FMAs.
 __device__ __forceinline__ float erf_as(float x) {
     const float ax = fabsf(x);

@@ -132,18 +132,49 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const resid_t* __re
 // contribution in bwq).  The sub-block therefore needs no GEMM: per row it is 12 dot products of
 // the centred row against LDS-resident vectors, a sigmoid per head, and a blend of the two value rows.
 template <int NJ>
-__global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int rows_per_block) {
+__global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int chunks_per_sample) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int d = NJ * 128, H = NJ * 2;
+    constexpr float inv_d = 1.0f / (float)d;
     float* wd = reinterpret_cast<float*>(smem);          // [H][d]  wq_label - wq_noise (gamma folded)
     float* vn = wd + H * d;                              // [d]     value row of the noise token
     float* vdiff = vn + d;                               // [d]     v_label - v_noise
     float* bw = vdiff + d;                               // [H]     beta contribution to the logit diff
 
-    const int blocks_per_sample = p.ntok / rows_per_block;
-    const int b = blockIdx.x / blocks_per_sample;
-    const int r0 = (blockIdx.x - b * blocks_per_sample) * rows_per_block;
+    // A workgroup owns one contiguous chunk of ROW PAIRS of one sample (balanced split, so the grid can be sized
+    // to exactly one resident round: 3 workgroups per CU); its four waves take the pairs round-robin.
+    const int b = blockIdx.x / chunks_per_sample;
+    const int ck = blockIdx.x - b * chunks_per_sample;
+    const int pairs = p.ntok >> 1;
+    const int pp0 = (int)((long)ck * pairs / chunks_per_sample);
+    const int pp1 = (int)((long)(ck + 1) * pairs / chunks_per_sample);
     const int tn = p.noise_row[b], tl = p.label_row[b];
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool upper = lane >= 32;
+    // input rows: normally the same rows; with CFG layer-0 sharing the cond and uncond samples read the one copy
+    const resid_t* xin = p.x_in ? p.x_in : p.x;
+    const size_t obase = (size_t)b * p.ntok;
+    const size_t ibase = p.x_in ? (size_t)(b % p.src_batch) * p.ntok : obase;
+
+    // Two rows per wave at a time (independent reduction chains fill the DPP wait states), with the next
+    // pair's HBM loads issued before the current pair is processed (the first pair's before the table fill).
+    float2 xr[2][NJ];
+    bf16x2 ar[2][NJ];
+    auto fetch = [&](size_t row, float2 (&xv)[NJ], bf16x2 (&av)[NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = j * 128 + 2 * lane;
+            xv[j] = rs_load2(xin + row * d + n);
+            av[j] = *reinterpret_cast<const bf16x2*>(p.att + row * d + n);
+        }
+    };
+    int pr = pp0 + wid;
+    if (pr < pp1) {
+        fetch(ibase + 2 * (size_t)pr, xr[0], ar[0]);
+        fetch(ibase + 2 * (size_t)pr + 1, xr[1], ar[1]);
+    }
 
     {
         const float4* wl = reinterpret_cast<const float4*>(p.wq + (size_t)tl * H * d);
@@ -161,134 +192,118 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
     }
     if (threadIdx.x < H) bw[threadIdx.x] = p.bwq[(size_t)tl * H + threadIdx.x] - p.bwq[(size_t)tn * H + threadIdx.x];
     __syncthreads();
-
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const bool upper = lane >= 32;
-    const int rows_per_wave = rows_per_block / 4;            // even
-    const size_t wrow0 = (size_t)b * p.ntok + r0 + wid * rows_per_wave;
-    // input rows: normally the same rows; with CFG layer-0 sharing the cond and uncond samples read the one copy
-    const resid_t* xin = p.x_in ? p.x_in : p.x;
-    const size_t irow0 = p.x_in ? (size_t)(b % p.src_batch) * p.ntok + r0 + wid * rows_per_wave : wrow0;
-
-    // Two rows per wave at a time (independent reduction chains fill the DPP wait states), with the next
-    // pair's HBM loads issued before the current pair is processed.
-    float2 xr[2][NJ];
-    bf16x2 ar[2][NJ];
-    auto fetch = [&](size_t row, float2 (&xv)[NJ], bf16x2 (&av)[NJ]) {
+    // lane's features of group j belong to head 2j + (lane >> 5)
+    float bwl[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = j * 128 + 2 * lane;
-            xv[j] = rs_load2(xin + row * d + n);
-            av[j] = *reinterpret_cast<const bf16x2*>(p.att + row * d + n);
-        }
-    };
-    fetch(irow0, xr[0], ar[0]);
-    fetch(irow0 + 1, xr[1], ar[1]);
-    for (int rr = 0; rr < rows_per_wave; rr += 2) {
-        float2 v[2][NJ];
+    for (int hh = 0; hh < NJ; ++hh) bwl[hh] = bw[2 * hh + (upper ? 1 : 0)];
+
+    for (; pr < pp1; pr += 4) {
+        f32x2 v[2][NJ];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                v[u][j].x = xr[u][j].x + (float)ar[u][j][0];        // x = SA(LN1 x) + x
-                v[u][j].y = xr[u][j].y + (float)ar[u][j][1];
+                v[u][j][0] = xr[u][j].x + (float)ar[u][j][0];        // x = SA(LN1 x) + x
+                v[u][j][1] = xr[u][j].y + (float)ar[u][j][1];
             }
-        const size_t row = wrow0 + rr;
-        if (rr + 2 < rows_per_wave) {
-            fetch(irow0 + rr + 2, xr[0], ar[0]);
-            fetch(irow0 + rr + 3, xr[1], ar[1]);
+        const size_t row = obase + 2 * (size_t)pr;
+        if (pr + 4 < pp1) {
+            fetch(ibase + 2 * (size_t)(pr + 4), xr[0], ar[0]);
+            fetch(ibase + 2 * (size_t)(pr + 4) + 1, xr[1], ar[1]);
         }
         if (p.sa_out) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    *reinterpret_cast<float2*>(p.sa_out + (row + u) * d + j * 128 + 2 * lane) = v[u][j];
+                    *reinterpret_cast<f32x2*>(p.sa_out + (row + u) * d + j * 128 + 2 * lane) = v[u][j];
         }
-        float s[2] = {0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) s[u] += v[u][j].x + v[u][j].y;
         float mean[2], rstd[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) mean[u] = wave_sum(s[u]) / (float)d;
-        float2 c[2][NJ];
-        float q[2] = {0.f, 0.f};
+        for (int u = 0; u < 2; ++u) {
+            f32x2 s2 = v[u][0];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int j = 1; j < NJ; ++j) s2 += v[u][j];
+            mean[u] = wave_sum(s2[0] + s2[1]) * inv_d;
+        }
+        f32x2 c[2][NJ];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x2 q2 = {0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                c[u][j].x = v[u][j].x - mean[u]; c[u][j].y = v[u][j].y - mean[u];
-                q[u] += c[u][j].x * c[u][j].x + c[u][j].y * c[u][j].y;
+                c[u][j] = v[u][j] - mean[u];
+                q2 = __builtin_elementwise_fma(c[u][j], c[u][j], q2);
             }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) rstd[u] = 1.0f / sqrtf(wave_sum(q[u]) / (float)d + kLnEps);
+            rstd[u] = __builtin_amdgcn_rsqf(fmaf(wave_sum(q2[0] + q2[1]), inv_d, kLnEps));
+        }
 
-        // per-head logit difference -> sigmoid weight of the label token.
-        // lane's features of group j belong to head 2j + (lane >> 5)
+        // per-head logit difference -> sigmoid weight of the label token.  Packed-fp32 FMAs over the lane's
+        // feature pairs; the cross-lane sums of a head PAIR share one v_permlane32_swap (lanes 0-31 finish
+        // head 2hh, lanes 32-63 head 2hh+1 -- exactly the head whose features each half holds).
         float plab[2][NJ];
 #pragma unroll
         for (int hh = 0; hh < NJ; ++hh) {
-            float part[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+            f32x2 acc[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
             const float* w0 = wd + (2 * hh) * d + 2 * lane;
             const float* w1 = w0 + d;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const float2 a = *reinterpret_cast<const float2*>(w0 + j * 128);
-                const float2 e = *reinterpret_cast<const float2*>(w1 + j * 128);
+                const f32x2 a = *reinterpret_cast<const f32x2*>(w0 + j * 128);
+                const f32x2 e = *reinterpret_cast<const f32x2*>(w1 + j * 128);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    part[u][0] = fmaf(c[u][j].x, a.x, fmaf(c[u][j].y, a.y, part[u][0]));
-                    part[u][1] = fmaf(c[u][j].x, e.x, fmaf(c[u][j].y, e.y, part[u][1]));
+                    acc[u][0] = __builtin_elementwise_fma(c[u][j], a, acc[u][0]);
+                    acc[u][1] = __builtin_elementwise_fma(c[u][j], e, acc[u][1]);
                 }
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const float d0 = wave_sum(part[u][0]) * rstd[u] + bw[2 * hh];
-                const float d1 = wave_sum(part[u][1]) * rstd[u] + bw[2 * hh + 1];
-                const float dl = upper ? d1 : d0;
+                const float p0 = acc[u][0][0] + acc[u][0][1], p1 = acc[u][1][0] + acc[u][1][1];
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+                const float dl = half_sum(__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * rstd[u] + bwl[hh];
                 plab[u][hh] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-dl * 1.44269504088896340736f));
             }
             __builtin_amdgcn_sched_barrier(0);     // keep the next head pair's 2 x NJ LDS reads from being hoisted (VGPRs)
         }
         // x += p_noise v_n + p_label v_l ; then LN3
-        float s3[2] = {0.f, 0.f};
+        float mean3[2], rstd3[2];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int n = j * 128 + 2 * lane;
-            const float2 a = *reinterpret_cast<const float2*>(vn + n);
-            const float2 dd = *reinterpret_cast<const float2*>(vdiff + n);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                v[u][j].x += fmaf(plab[u][j], dd.x, a.x);
-                v[u][j].y += fmaf(plab[u][j], dd.y, a.y);
-                rs_store2(p.x + (row + u) * d + n, v[u][j]);
-                s3[u] += v[u][j].x + v[u][j].y;
-            }
-        }
-        float mean3[2], rstd3[2], q3[2] = {0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) mean3[u] = wave_sum(s3[u]) / (float)d;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < 2; ++u) {
+            f32x2 s2 = {0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                v[u][j].x -= mean3[u]; v[u][j].y -= mean3[u];
-                q3[u] += v[u][j].x * v[u][j].x + v[u][j].y * v[u][j].y;
+                const int n = j * 128 + 2 * lane;
+                const f32x2 a = *reinterpret_cast<const f32x2*>(vn + n);
+                const f32x2 dd = *reinterpret_cast<const f32x2*>(vdiff + n);
+                const f32x2 pl = {plab[u][j], plab[u][j]};
+                v[u][j] += __builtin_elementwise_fma(pl, dd, a);
+                rs_store2(p.x + (row + u) * d + n, make_float2(v[u][j][0], v[u][j][1]));
+                s2 += v[u][j];
             }
+            mean3[u] = wave_sum(s2[0] + s2[1]) * inv_d;
+        }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) rstd3[u] = 1.0f / sqrtf(wave_sum(q3[u]) / (float)d + kLnEps);
+        for (int u = 0; u < 2; ++u) {
+            f32x2 q2 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                v[u][j] -= mean3[u];
+                q2 = __builtin_elementwise_fma(v[u][j], v[u][j], q2);
+            }
+            rstd3[u] = __builtin_amdgcn_rsqf(fmaf(wave_sum(q2[0] + q2[1]), inv_d, kLnEps));
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = j * 128 + 2 * lane;
-            const float2 gg = *reinterpret_cast<const float2*>(p.ln3_w + n);
-            const float2 bb = *reinterpret_cast<const float2*>(p.ln3_b + n);
+            const f32x2 gg = *reinterpret_cast<const f32x2*>(p.ln3_w + n);
+            const f32x2 bb = *reinterpret_cast<const f32x2*>(p.ln3_b + n);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                const f32x2 r = __builtin_elementwise_fma(v[u][j] * rstd3[u], gg, bb);
                 bf16x2 o;
-                o[0] = (bf16)(v[u][j].x * rstd3[u] * gg.x + bb.x);
-                o[1] = (bf16)(v[u][j].y * rstd3[u] * gg.y + bb.y);
+                o[0] = (bf16)r[0];
+                o[1] = (bf16)r[1];
                 *reinterpret_cast<bf16x2*>(p.xn3 + (row + u) * d + n) = o;
             }
         }
@@ -545,10 +560,24 @@ void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf1
 }
 
 void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
-    const int rpb = 32;                 // 4 waves x 8 rows; ~43 KB of LDS per workgroup -> 3 workgroups per CU
+    // ~43 KB of LDS per workgroup -> 3 workgroups per CU.  Split each sample's row pairs into the number of
+    // chunks that makes the grid ONE full resident round (768 workgroups on 256 CUs) when the batch allows,
+    // else k rounds of <= ~48 rows per workgroup; a partial extra round costs as much as a full one.
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        slots = 3 * (cus > 0 ? cus : 256);
+    }
+    const long rows = (long)p.batch * p.ntok;
+    const long k = (rows + (long)slots * 48 - 1) / ((long)slots * 48);
+    long cps = slots * k / p.batch;
+    const long max_cps = p.ntok / 8 > 0 ? p.ntok / 8 : 1;          // at least one row pair per wave
+    if (cps > max_cps) cps = max_cps;
+    if (cps < 1) cps = 1;
     const int lds = (p.heads * p.d + 2 * p.d + p.heads) * (int)sizeof(float);
-    dim3 grid(p.batch * (p.ntok / rpb));
-    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(cross_row_kernel<NJ>, grid, dim3(256), lds, s, p, rpb));
+    dim3 grid((unsigned)(p.batch * cps));
+    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(cross_row_kernel<NJ>, grid, dim3(256), lds, s, p, (int)cps));
 }
 
 void launch_tail(const TailParams& p, hipStream_t s) {

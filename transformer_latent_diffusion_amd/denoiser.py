@@ -10,8 +10,9 @@ Keeps the constructor and call contract the reference's sampler, pipeline and te
     model.parameters()                              fp32 tensors (count matches the reference)
     model.n_channels, model.image_size              ints
 
-Arithmetic runs in ``libtld_hip.so`` (bf16 MFMA operands, fp32 accumulation, fp32 residual stream and
-fp32 conditioning path); Python owns configuration, weight hand-over and tensors only.  There is no
+Arithmetic runs in ``libtld_hip.so`` (bf16 MFMA operands, fp32 accumulation, bf16 residual stream --
+fp32 when built with ``-DTLD_RESID_FP32`` -- and fp32 conditioning path); Python owns configuration,
+weight hand-over and tensors only.  There is no
 CPU or eager-PyTorch fallback: calling the model without a HIP device raises.
 """
 from __future__ import annotations
