@@ -57,18 +57,20 @@ __device__ __forceinline__ float half_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp, one v_exp, six FMAs.
+// erf by Abramowitz-Stegun 7.1.28:  1 - (1 + a1 x + ... + a6 x^6)^-16  (|error| <= 3e-7; 9e-7 measured in fp32
+// through the GELU).  One transcendental (v_rcp) + six FMAs + four squarings; the 7.1.26 form used before
+// needed v_rcp AND v_exp, and quarter-rate transcendentals were ~40 % of the fused depthwise epilogue.
 __device__ __forceinline__ float erf_as(float x) {
     const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float e = __builtin_amdgcn_exp2f(-ax * ax * 1.44269504088896340736f);
-    const float r = fmaf(-p, e, 1.0f);
-    return copysignf(r, x);
+    float p = fmaf(0.0000430638f, ax, 0.0002765672f);
+    p = fmaf(p, ax, 0.0001520143f);
+    p = fmaf(p, ax, 0.0092705272f);
+    p = fmaf(p, ax, 0.0422820123f);
+    p = fmaf(p, ax, 0.0705230784f);
+    p = fmaf(p, ax, 1.0f);
+    float r = __builtin_amdgcn_rcpf(p);
+    r *= r; r *= r; r *= r; r *= r;
+    return copysignf(1.0f - r, x);
 }
 
 // exact-erf GELU (nn.GELU default): 0.5 x (1 + erf(x / sqrt 2)).  `precise` uses the libm-grade erff
@@ -78,6 +80,22 @@ __device__ __forceinline__ float gelu_erf(float x) {
 }
 __device__ __forceinline__ float gelu_erf_fast(float x) {
     return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
+// two-lane form (v_pk_* arithmetic; v_rcp per component)
+__device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
+    const f32x2 z = x * 0.70710678118654752440f;
+    const f32x2 az = __builtin_elementwise_abs(z);
+    f32x2 p = __builtin_elementwise_fma(f32x2{0.0000430638f, 0.0000430638f}, az, f32x2{0.0002765672f, 0.0002765672f});
+    p = __builtin_elementwise_fma(p, az, f32x2{0.0001520143f, 0.0001520143f});
+    p = __builtin_elementwise_fma(p, az, f32x2{0.0092705272f, 0.0092705272f});
+    p = __builtin_elementwise_fma(p, az, f32x2{0.0422820123f, 0.0422820123f});
+    p = __builtin_elementwise_fma(p, az, f32x2{0.0705230784f, 0.0705230784f});
+    p = __builtin_elementwise_fma(p, az, f32x2{1.0f, 1.0f});
+    f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+    r *= r; r *= r; r *= r; r *= r;
+    const f32x2 e = {copysignf(1.0f - r[0], z[0]), copysignf(1.0f - r[1], z[1])};       // erf(z)
+    const f32x2 hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, e, hx);
 }
 // (A transcendental-free degree-9 polynomial erf was measured ~4 % SLOWER end to end: its 10-deep dependent FMA
 // chain is latency-bound at the 2 waves/SIMD of the fused GEMM epilogue.)
@@ -144,6 +162,7 @@ struct GemmParams {
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
     unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop
+    int dbg_epi;                  // experiment knob, builds with -DTLD_DBG_EPI only (TLD_EPI_DBG bit mask, see tld_gemm.hip)
 };
 
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s);

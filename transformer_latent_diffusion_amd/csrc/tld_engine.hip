@@ -612,6 +612,16 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     g.c_f32 = res; g.ldc = N; g.out_bf16 = out; g.ldo = epilogue == EPI_QKV ? 2 * (N / 3) : N; g.vt = vt;
     g.ntok = ntok > 0 ? ntok : 1; g.d = N / 3; g.bias = bias; g.resid = reinterpret_cast<resid_t*>(res); g.ldr = N;
     g.dbg_no_dma = (getenv("TLD_GEMM_DBG") && atoi(getenv("TLD_GEMM_DBG")) == 2) ? 1 : 0;
+    g.dbg_epi = getenv("TLD_EPI_DBG") ? atoi(getenv("TLD_EPI_DBG")) : 0;
+    float *dww = nullptr;
+    if (epilogue == EPI_UP_DWCONV) {
+        if (M % 256 || N % 256) return fail(TLD_ERR_INVALID, "fused depthwise epilogue needs M, N multiples of 256");
+        HIP_TRY(hipMalloc(&dww, (size_t)N * 10 * 4));
+        std::vector<float> hw((size_t)N * 10);
+        for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0.05f + 0.01f * (float)(i % 7);
+        HIP_TRY(hipMemcpy(dww, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+        g.dw_w9c = dww; g.dw_b = dww + (size_t)N * 9;
+    }
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
     unsigned long long* trace = nullptr;
@@ -643,7 +653,7 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
         hipFree(trace);
     }
     hipEventDestroy(a); hipEventDestroy(b);
-    hipFree(A); hipFree(W); hipFree(out); hipFree(vt); hipFree(bias); hipFree(res);
+    hipFree(A); hipFree(W); hipFree(out); hipFree(vt); hipFree(bias); hipFree(res); hipFree(dww);
     HIP_TRY(hipGetLastError());
     return TLD_OK;
 }

@@ -10,6 +10,14 @@
 #include <cstring>
 #include <type_traits>
 
+// -DTLD_DBG_EPI builds honour GemmParams::dbg_epi in the fused depthwise epilogue (cost attribution):
+//   1 = no global stores, 2 = identity instead of GELU, 4 = skip the conv phase, 8 = skip the LDS image write too
+#ifdef TLD_DBG_EPI
+#define TLD_EPI_BIT(b) ((p.dbg_epi & (b)) != 0)
+#else
+#define TLD_EPI_BIT(b) false
+#endif
+
 #ifndef TLD_GLDS_AUX
 #define TLD_GLDS_AUX 0      // cache-policy bits of the tile DMA (experiment knob: 2 = nt; measured slower)
 #endif
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 // kernel disappears.  16-B chunks of a token row are XOR-swizzled with (token & 31).
                 static_assert(BN == 256, "fused depthwise epilogue is written for 256-column tiles");
                 char* H = smem;
+                if (!TLD_EPI_BIT(8))
 #pragma unroll
                 for (int i = 0; i < G::TM; ++i)
 #pragma unroll
@@ -281,61 +290,83 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             *reinterpret_cast<bf16x4*>(H + tok * 512 + ((((cl >> 3) ^ (tok & 31)) << 4) | ((cl & 7) << 1))) = pk;
                         }
                 __builtin_amdgcn_s_barrier();
-                {
+                if (!TLD_EPI_BIT(4)) {
                     const int cq = threadIdx.x & 63;                     // channel quad (64 per token row)
                     const int c0 = n0 + cq * 4;
-                    float4 w[9];
+                    // packed-fp32 arithmetic throughout: channel pairs {c0,c0+1} and {c0+2,c0+3} ride in f32x2 registers
+                    f32x2 w[9][2], bs[2];
 #pragma unroll
-                    for (int k9 = 0; k9 < 9; ++k9) w[k9] = *reinterpret_cast<const float4*>(p.dw_w9c + (size_t)k9 * p.N + c0);
-                    const float4 bs = *reinterpret_cast<const float4*>(p.dw_b + c0);
-#pragma unroll 1
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const int irow = (threadIdx.x >> 6) + rr * 8;    // image row 0..15
-                        const bool up_ok = irow > 0, dn_ok = irow < 15;
-                        auto col = [&](int jj, float4 (&c)[3]) {
-                            const bool jok = jj >= 0 && jj < 16;
+                    for (int k9 = 0; k9 < 9; ++k9) {
+                        const float4 t = *reinterpret_cast<const float4*>(p.dw_w9c + (size_t)k9 * p.N + c0);
+                        w[k9][0] = f32x2{t.x, t.y}; w[k9][1] = f32x2{t.z, t.w};
+                    }
+                    {
+                        const float4 t = *reinterpret_cast<const float4*>(p.dw_b + c0);
+                        bs[0] = f32x2{t.x, t.y}; bs[1] = f32x2{t.z, t.w};
+                    }
+                    // each thread walks TWO image rows (irow, irow + 8) in lockstep: two independent window/FMA/GELU
+                    // chains per thread -- with 2 waves per SIMD the single-row form was latency-bound
+                    const int irow0 = threadIdx.x >> 6;                  // image rows irow0 and irow0 + 8
+                    auto col = [&](int jj, f32x2 (&c)[2][3][2]) {
+                        const bool jok = jj >= 0 && jj < 16;
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            const int irow = irow0 + rr * 8;
 #pragma unroll
                             for (int du = 0; du < 3; ++du) {
-                                const bool ok = jok && (du == 1 || (du == 0 ? up_ok : dn_ok));
+                                const int ir = irow + du - 1;
+                                const bool ok = jok && ir >= 0 && ir < 16;
                                 if (ok) {
-                                    const int tok = (irow + du - 1) * 16 + jj;
+                                    const int tok = ir * 16 + jj;
                                     const bf16x4 v = *reinterpret_cast<const bf16x4*>(
                                         H + tok * 512 + ((((cq >> 1) ^ (tok & 31)) << 4) | ((cq & 1) << 3)));
-                                    c[du] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+                                    c[rr][du][0] = f32x2{(float)v[0], (float)v[1]};
+                                    c[rr][du][1] = f32x2{(float)v[2], (float)v[3]};
                                 } else {
-                                    c[du] = make_float4(0.f, 0.f, 0.f, 0.f);
+                                    c[rr][du][0] = f32x2{0.f, 0.f};
+                                    c[rr][du][1] = f32x2{0.f, 0.f};
                                 }
                             }
-                        };
-                        bf16* dst = p.out_bf16 + ((size_t)m0 + irow * 16) * p.ldo + c0;
-                        auto emit = [&](const float4 (&L)[3], const float4 (&Mc)[3], const float4 (&R)[3], int jj) {
-                            float4 part[3];
-#pragma unroll
-                            for (int du = 0; du < 3; ++du) {
-                                const float4 w0 = w[du * 3 + 0], w1 = w[du * 3 + 1], w2 = w[du * 3 + 2];
-                                part[du].x = fmaf(w2.x, R[du].x, fmaf(w1.x, Mc[du].x, w0.x * L[du].x));
-                                part[du].y = fmaf(w2.y, R[du].y, fmaf(w1.y, Mc[du].y, w0.y * L[du].y));
-                                part[du].z = fmaf(w2.z, R[du].z, fmaf(w1.z, Mc[du].z, w0.z * L[du].z));
-                                part[du].w = fmaf(w2.w, R[du].w, fmaf(w1.w, Mc[du].w, w0.w * L[du].w));
-                            }
-                            bf16x4 o;
-                            o[0] = (bf16)TLD_DW_GELU((part[0].x + part[1].x) + (part[2].x + bs.x));
-                            o[1] = (bf16)TLD_DW_GELU((part[0].y + part[1].y) + (part[2].y + bs.y));
-                            o[2] = (bf16)TLD_DW_GELU((part[0].z + part[1].z) + (part[2].z + bs.z));
-                            o[3] = (bf16)TLD_DW_GELU((part[0].w + part[1].w) + (part[2].w + bs.w));
-                            if (m0 + irow * 16 + jj < p.M) *reinterpret_cast<bf16x4*>(dst + (size_t)jj * p.ldo) = o;
-                        };
-                        float4 c0v[3], c1v[3], c2v[3];
-                        col(-1, c0v);
-                        col(0, c1v);
-                        int jj = 0;
-                        for (; jj + 3 <= 16; jj += 3) {
-                            col(jj + 1, c2v); emit(c0v, c1v, c2v, jj);
-                            col(jj + 2, c0v); emit(c1v, c2v, c0v, jj + 1);
-                            col(jj + 3, c1v); emit(c2v, c0v, c1v, jj + 2);
                         }
-                        col(jj + 1, c2v); emit(c0v, c1v, c2v, jj);       // jj == 15
+                    };
+                    bf16* dst0 = p.out_bf16 + ((size_t)m0 + irow0 * 16) * p.ldo + c0;
+                    auto emit = [&](const f32x2 (&L)[2][3][2], const f32x2 (&Mc)[2][3][2], const f32x2 (&R)[2][3][2], int jj) {
+                        f32x2 a[2][2];
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) { a[rr][0] = bs[0]; a[rr][1] = bs[1]; }
+                        // one FMA chain per (row, channel pair), seeded with the conv bias
+#pragma unroll
+                        for (int du = 0; du < 3; ++du)
+#pragma unroll
+                            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+                                    a[rr][h2] = __builtin_elementwise_fma(w[du * 3 + 0][h2], L[rr][du][h2], a[rr][h2]);
+                                    a[rr][h2] = __builtin_elementwise_fma(w[du * 3 + 1][h2], Mc[rr][du][h2], a[rr][h2]);
+                                    a[rr][h2] = __builtin_elementwise_fma(w[du * 3 + 2][h2], R[rr][du][h2], a[rr][h2]);
+                                }
+                        if (!TLD_EPI_BIT(2)) {
+#pragma unroll
+                            for (int rr = 0; rr < 2; ++rr) { a[rr][0] = gelu_erf_fast2(a[rr][0]); a[rr][1] = gelu_erf_fast2(a[rr][1]); }
+                        }
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            bf16x4 o;
+                            o[0] = (bf16)a[rr][0][0]; o[1] = (bf16)a[rr][0][1]; o[2] = (bf16)a[rr][1][0]; o[3] = (bf16)a[rr][1][1];
+                            if (m0 + (irow0 + rr * 8) * 16 + jj < (TLD_EPI_BIT(1) ? -1 : p.M))
+                                *reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 128 + jj) * p.ldo) = o;
+                        }
+                    };
+                    f32x2 c0v[2][3][2], c1v[2][3][2], c2v[2][3][2];
+                    col(-1, c0v);
+                    col(0, c1v);
+                    int jj = 0;
+                    for (; jj + 3 <= 16; jj += 3) {
+                        col(jj + 1, c2v); emit(c0v, c1v, c2v, jj);
+                        col(jj + 2, c0v); emit(c1v, c2v, c0v, jj + 1);
+                        col(jj + 3, c1v); emit(c2v, c0v, c1v, jj + 2);
                     }
+                    col(jj + 1, c2v); emit(c0v, c1v, c2v, jj);       // jj == 15
                 }
                 // the ring restarts for the next tile: its first K-step could not be prefetched (LDS was the image)
                 __builtin_amdgcn_s_barrier();
@@ -481,7 +512,14 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
 
 }  // namespace
 
-void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s) {
+void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
+#ifdef TLD_DBG_EPI
+    static const int dbg_epi_env = getenv("TLD_EPI_DBG") ? atoi(getenv("TLD_EPI_DBG")) : 0;
+    GemmParams p = p_in;
+    if (!p.dbg_epi) p.dbg_epi = dbg_epi_env;
+#else
+    const GemmParams& p = p_in;
+#endif
     // BN = 256 unless that leaves the last round of workgroups mostly empty on 256 CUs; then prefer the widest
     // tile whose workgroup count is a whole number of rounds (192 for the residual epilogue), else 128.
     const long ntm = (p.M + 255) / 256;
