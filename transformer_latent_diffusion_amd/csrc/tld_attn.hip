@@ -206,6 +206,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn1_kernel(const bf16* __restric
     const int twod = 2 * d;
     const size_t row_base = (size_t)b * ntok;
 
+    // Q fragments of the wave's first query tile: issued before the K/V staging waits, and inside the loop the
+    // next tile's are issued before the current tile is processed (the load used to sit in front of its MFMAs)
+    bf16x8 qnext[4];
+    auto load_q = [&](int qt, bf16x8 (&q)[4]) {
+        const bf16* qp = qk + (row_base + (wid * QT + qt) * 32 + l31) * twod + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) q[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    };
+    load_q(0, qnext);
     {   // K: DMA, source-side swizzle
         const bf16* kbase = qk + row_base * twod + d + h * 64;
         constexpr int KP = KC / 8 / NW;
@@ -234,11 +243,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn1_kernel(const bf16* __restric
     for (int qt = 0; qt < QT; ++qt) {
         const int q0 = (wid * QT + qt) * 32;
         bf16x8 qf[4];
-        {
-            const bf16* qp = qk + (row_base + q0 + l31) * twod + h * 64 + hi * 8;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-        }
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = qnext[ks];
+        if (qt + 1 < QT) load_q(qt + 1, qnext);
         f32x16 st[KT];
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
