@@ -350,6 +350,13 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     if (c->max_batch <= 0 || c->n_layers <= 0 || c->mlp_multiplier <= 0 || c->text_emb_size <= 0)
         return fail(TLD_ERR_INVALID, "non-positive size in config");
     if ((c->mlp_multiplier * c->embed_dim) % 64) return fail(TLD_ERR_INVALID, "hidden width must be a multiple of 64");
+    {   // the GEMM tile DMA addresses operands with 32-bit byte offsets
+        const int64_t g = c->image_size / c->patch_size;
+        const int64_t hid_bytes = (int64_t)c->max_batch * g * g * c->mlp_multiplier * c->embed_dim * 2;
+        if (hid_bytes >= (int64_t)1 << 32)
+            return fail(TLD_ERR_INVALID, "max_batch=%d: the hidden activation (%lld bytes) must stay below 4 GiB; "
+                        "run larger batches as several calls", c->max_batch, (long long)hid_bytes);
+    }
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (c->device_id < 0 || c->device_id >= ndev) return fail(TLD_ERR_INVALID, "device_id %d out of range (%d devices)", c->device_id, ndev);
@@ -586,6 +593,8 @@ int tld_sample(tld_engine* e, const void* x_T, const void* labels, const float* 
 int tld_debug_gemm_bf16(const void* a, const void* w, float* c, int32_t M, int32_t N, int32_t K, void* hip_stream) {
     if (!a || !w || !c) return fail(TLD_ERR_INVALID, "null argument");
     if (K % 64 || K <= 0 || M <= 0 || N <= 0) return fail(TLD_ERR_INVALID, "need K %% 64 == 0 and positive sizes");
+    if ((int64_t)M * K * 2 >= (int64_t)1 << 32 || (int64_t)N * K * 2 >= (int64_t)1 << 32)
+        return fail(TLD_ERR_INVALID, "operands must be smaller than 4 GiB");
     GemmParams g{};
     g.A = static_cast<const bf16*>(a); g.lda = K; g.W = static_cast<const bf16*>(w); g.ldw = K;
     g.M = M; g.N = N; g.K = K; g.c_f32 = c; g.ldc = N;
@@ -597,6 +606,8 @@ int tld_debug_gemm_bf16(const void* a, const void* w, float* c, int32_t M, int32
 int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t ntok, int32_t iters,
                          double* avg_ms) {
     if (!avg_ms || M <= 0 || N <= 0 || K <= 0 || K % 64 || iters <= 0) return fail(TLD_ERR_INVALID, "bad argument");
+    if ((int64_t)M * K * 2 >= (int64_t)1 << 32 || (int64_t)N * K * 2 >= (int64_t)1 << 32)
+        return fail(TLD_ERR_INVALID, "operands must be smaller than 4 GiB");
     if (epilogue == EPI_QKV && (N % 3 || ntok <= 0 || M % ntok)) return fail(TLD_ERR_INVALID, "QKV epilogue needs N = 3d, M %% ntok == 0");
     bf16 *A = nullptr, *W = nullptr, *out = nullptr, *vt = nullptr;
     float *bias = nullptr, *res = nullptr;   // res doubles as fp32 C and as the residual buffer (sized for fp32)

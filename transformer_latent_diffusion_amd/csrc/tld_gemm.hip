@@ -54,35 +54,6 @@ struct G256 {
     static constexpr int A_PIECES = BM / 8 / 8, B_PIECES = BN / 8 / 8;     // 1-KiB DMA pieces per wave per K-step
 };
 
-// one 1-KiB DMA piece (8 rows x 128 B) of a [rows x 64] bf16 tile; piece index is wave-uniform
-__device__ __forceinline__ void stage64_piece(const bf16* __restrict__ g, int ld, int row0, int row_max, int k0,
-                                              char* lds_tile, int piece, int lane) {
-    const int r = piece * 8 + (lane >> 3);
-    const int cphys = lane & 7;
-    const int clog = cphys ^ ((r >> 1) & 7);
-    int gr = row0 + r;
-    gr = gr < row_max ? gr : row_max - 1;
-    const bf16* src = g + (size_t)gr * ld + k0 + clog * 8;
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lds_tile + piece * 1024), 16, 0, TLD_GLDS_AUX);
-}
-
-template <int PIECES>
-__device__ __forceinline__ void stage64(const bf16* __restrict__ g, int ld, int row0, int row_max, int k0,
-                                        char* lds_tile, int wid, int lane) {
-#pragma unroll
-    for (int it = 0; it < PIECES; ++it) {
-        const int piece = wid * PIECES + it;
-        const int r = piece * 8 + (lane >> 3);
-        const int cphys = lane & 7;
-        const int clog = cphys ^ ((r >> 1) & 7);
-        int gr = row0 + r;
-        gr = gr < row_max ? gr : row_max - 1;
-        const bf16* src = g + (size_t)gr * ld + k0 + clog * 8;
-        char* dst = lds_tile + piece * 1024;                    // wave-uniform; lane i lands at +16*i
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, TLD_GLDS_AUX);
-    }
-}
-
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -144,10 +115,51 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     if (my_tiles == 0) return;
 
     const int nk = p.K / G::BK;
-    auto issue = [&](int m0, int n0, int k, int g) {
+    // DMA addressing: a uniform 64-bit base (operand + K offset, SGPRs) plus one 32-bit byte offset per piece and
+    // lane (row clamp, row pitch and the source-side swizzle), recomputed once per tile -- per K-step and piece the
+    // only VALU work is the load itself.  (Operands are < 4 GiB: checked at launch.)
+    unsigned voffA[G::A_PIECES], voffB[G::B_PIECES];
+    auto set_offsets = [&](int tm0, int tn0) {
+        // (the empty asm statements keep the compiler from hoisting the lane-only sub-expressions out of the tile
+        // loop as 64-bit loop invariants -- it then spilled them inside the K loop)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int q2 = 0; q2 < G::A_PIECES; ++q2) {
+            const int r = (wid * G::A_PIECES + q2) * 8 + (ln >> 3);
+            const int clog = (ln & 7) ^ ((r >> 1) & 7);
+            int gr = tm0 + r;
+            gr = gr < p.M ? gr : p.M - 1;
+            unsigned v = __umul24((unsigned)gr, (unsigned)(p.lda * 2)) + (unsigned)(clog * 16);   // rows, pitch < 2^24
+            asm volatile("" : "+v"(v));
+            voffA[q2] = v;
+        }
+#pragma unroll
+        for (int q2 = 0; q2 < G::B_PIECES; ++q2) {
+            const int r = (wid * G::B_PIECES + q2) * 8 + (ln >> 3);
+            const int clog = (ln & 7) ^ ((r >> 1) & 7);
+            int gr = tn0 + r;
+            gr = gr < p.N ? gr : p.N - 1;
+            unsigned v = __umul24((unsigned)gr, (unsigned)(p.ldw * 2)) + (unsigned)(clog * 16);
+            asm volatile("" : "+v"(v));
+            voffB[q2] = v;
+        }
+    };
+    auto dma_piece = [&](int q2, int kbyte, char* st) {       // q2 < A_PIECES: A piece, else W piece; kbyte uniform
+        if (q2 < G::A_PIECES) {
+            const char* base = reinterpret_cast<const char*>(p.A) + kbyte;
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + voffA[q2]), (lptr_t)(st + (wid * G::A_PIECES + q2) * 1024), 16, 0, TLD_GLDS_AUX);
+        } else {
+            const char* base = reinterpret_cast<const char*>(p.W) + kbyte;
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + voffB[q2 - G::A_PIECES]),
+                                             (lptr_t)(st + G::A_BYTES + (wid * G::B_PIECES + (q2 - G::A_PIECES)) * 1024), 16, 0, TLD_GLDS_AUX);
+        }
+    };
+    auto issue = [&](int m0, int n0, int g) {                 // K-step 0 of a tile, all pieces at once
         char* st = smem + (g & 1) * G::STAGE_BYTES;
-        stage64<G::A_PIECES>(p.A, p.lda, m0, p.M, k * G::BK, st, wid, lane);
-        stage64<G::B_PIECES>(p.W, p.ldw, n0, p.N, k * G::BK, st + G::A_BYTES, wid, lane);
+        set_offsets(m0, n0);
+#pragma unroll
+        for (int q2 = 0; q2 < G::A_PIECES + G::B_PIECES; ++q2) dma_piece(q2, 0, st);
     };
     auto load_frags = [&](const char* st, int ks, bf16x8 (&a)[G::TM], bf16x8 (&b)[G::TN]) {
         const int kc = ks * 2 + hi;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 
     int m0, n0;
     tile_coords(0, m0, n0);
-    issue(m0, n0, 0, 0);
+    issue(m0, n0, 0);
     int g = 0;                                        // global K-step counter (ring position)
     for (int it = 0; it < my_tiles; ++it) {
         int m0n = 0, n0n = 0;
@@ -207,15 +219,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
                 const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV);
-                const int pm0 = (k + 1 < nk) ? m0 : m0n, pn0 = (k + 1 < nk) ? n0 : n0n;
-                const int pk = (k + 1 < nk) ? (k + 1) * G::BK : 0;
+                const int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
+                if (k + 1 == nk && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
                 auto pieces = [&](int lo, int hi_) {
                     if (!more || p.dbg_no_dma) return;
 #pragma unroll
                     for (int q2 = 0; q2 < NP; ++q2) {
                         if (q2 < lo || q2 >= hi_) continue;
-                        if (q2 < G::A_PIECES) stage64_piece(p.A, p.lda, pm0, p.M, pk, nst, wid * G::A_PIECES + q2, lane);
-                        else stage64_piece(p.W, p.ldw, pn0, p.N, pk, nst + G::A_BYTES, wid * G::B_PIECES + (q2 - G::A_PIECES), lane);
+                        dma_piece(q2, pkb, nst);
                     }
                 };
                 load_frags(st, 0, a0, b0);
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 }
                 // the ring restarts for the next tile: its first K-step could not be prefetched (LDS was the image)
                 __builtin_amdgcn_s_barrier();
-                if (has_next) issue(m0n, n0n, 0, g);
+                if (has_next) issue(m0n, n0n, g);
             } else if constexpr (EPI == EPI_BIAS_RESID) {
                 constexpr int P = 32 * 4 + 16;      // one 32x32 fp32 tile, padded pitch
 #pragma unroll
@@ -512,6 +523,24 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
 
 }  // namespace
 
+namespace {
+// BN = 256 unless that leaves the last round of workgroups mostly empty on 256 CUs; then prefer the widest
+// tile whose workgroup count is a whole number of rounds (192 for the residual epilogue), else 128.
+int choose_bn(long M, long N, int epilogue) {
+    const long ntm = (M + 255) / 256;
+    const long blocks256 = ntm * ((N + 255) / 256);
+    const bool narrow = (N % 256 != 0) || (blocks256 % 256 != 0 && blocks256 < 3 * 256);
+    static const char* force = getenv("TLD_GEMM_BN");             // experiment knob
+    int bn = narrow ? 128 : 256;
+    if (narrow && epilogue == EPI_BIAS_RESID && N % 192 == 0 && (ntm * (N / 192)) % 256 == 0) bn = 192;
+    if (force) bn = atoi(force);
+    if (epilogue == EPI_UP_DWCONV) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
+    if (bn == 192 && (epilogue != EPI_BIAS_RESID || N % 192)) bn = 128;
+    if (bn != 256 && bn != 192) bn = 128;
+    return bn;
+}
+}  // namespace
+
 void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
 #ifdef TLD_DBG_EPI
     static const int dbg_epi_env = getenv("TLD_EPI_DBG") ? atoi(getenv("TLD_EPI_DBG")) : 0;
@@ -520,17 +549,7 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
 #else
     const GemmParams& p = p_in;
 #endif
-    // BN = 256 unless that leaves the last round of workgroups mostly empty on 256 CUs; then prefer the widest
-    // tile whose workgroup count is a whole number of rounds (192 for the residual epilogue), else 128.
-    const long ntm = (p.M + 255) / 256;
-    const long blocks256 = ntm * ((p.N + 255) / 256);
-    const bool narrow = (p.N % 256 != 0) || (blocks256 % 256 != 0 && blocks256 < 3 * 256);
-    static const char* force = getenv("TLD_GEMM_BN");             // experiment knob
-    int bn = narrow ? 128 : 256;
-    if (narrow && epilogue == EPI_BIAS_RESID && p.N % 192 == 0 && (ntm * (p.N / 192)) % 256 == 0) bn = 192;
-    if (force) bn = atoi(force);
-    if (epilogue == EPI_UP_DWCONV) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
-    if (bn == 192 && (epilogue != EPI_BIAS_RESID || p.N % 192)) bn = 128;
+    const int bn = choose_bn(p.M, p.N, epilogue);
     // (A column-split QKV launch -- 8 tile-columns of 256 as 4 whole rounds + the 9th as 128-wide tiles -- was
     // measured: 109.8 + 27.8 us vs 134 us for the single 4.5-round launch; a one-round launch pays ~12 us of
     // ramp/drain, so the half-empty fifth round is the cheaper tail.)
