@@ -2,8 +2,8 @@
 # HBM-side traffic of every kernel of one bench step, from PMC counters (separate passes for FETCH_SIZE and
 # WRITE_SIZE as the microarch guide prescribes; counters only -- no tracing flags on these runs).
 # usage (on the GPU box, from the repo root): tools/pmc_traffic.sh gpurun_out/pmc_traffic
-OUT=$1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+case $1 in /*) OUT=$1;; *) OUT=$R/$1;; esac
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for CNT in FETCH_SIZE WRITE_SIZE; do
