@@ -28,7 +28,6 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;   // (1/sqrt(64)) * log2(e)
 

@@ -11,6 +11,7 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // Residual stream dtype: bf16, as in the reference's own bf16 mode (x never leaves bf16 there either).  All
@@ -137,6 +138,22 @@ __device__ __forceinline__ void rs_store4(resid_t* p, float4 v) {
 #define TLD_DW_GELU gelu_erf_fast
 #endif
 
+// The MLP hidden activation (201 MB per layer, written by the up-projection epilogue) is stored nontemporal: a plain
+// store leaves 128 KB of dirty lines per tile in the XCD's 4 MB L2 and pushes the A / W tiles its 32 workgroups
+// share back out to the fabric (PMC: L2-miss traffic 1.7x the algorithmic bytes).  Measured, same box:
+//   hidden NT            +1.4 % end to end (its consumer, the down GEMM, gains most: 184 -> 174 us)
+//   q|k, v^T NT as well  -0.9 % (attention then misses L2 on its inputs: 50 -> 54 us) -> those stay plain
+//   8-B NT stores in the row kernels: attention 50 -> 110 us (partial lines are not combined) -> plain
+//   residual read-modify-write of the down GEMM NT: no change -> plain
+// -DTLD_NT_STORES=0 restores plain stores everywhere.
+#ifndef TLD_NT_STORES
+#define TLD_NT_STORES 1
+#endif
+#if TLD_NT_STORES
+#define TLD_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define TLD_STORE(ptr, val) (*(ptr) = (val))
+#endif
 // ---- launch descriptors ------------------------------------------------------------------------
 
 enum GemmEpilogue {

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             bf16x4 o;
                             o[0] = (bf16)a[rr][0][0]; o[1] = (bf16)a[rr][0][1]; o[2] = (bf16)a[rr][1][0]; o[3] = (bf16)a[rr][1][1];
                             if (m0 + (irow0 + rr * 8) * 16 + jj < (TLD_EPI_BIT(1) ? -1 : p.M))
-                                *reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 128 + jj) * p.ldo) = o;
+                                TLD_STORE(reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 128 + jj) * p.ldo), o);
                         }
                     };
                     f32x2 c0v[2][3][2], c1v[2][3][2], c2v[2][3][2];
@@ -440,10 +440,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         for (int itr = 0; itr < 4; ++itr) {
                             const int idx = itr * 64 + lane;
                             const int rl = idx >> 3, ch = idx & 7;
-                            const uint4 v = *reinterpret_cast<const uint4*>(ws + rl * P + ((ch ^ (rl & 7)) << 4));
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(ws + rl * P + ((ch ^ (rl & 7)) << 4));
                             const int row = row0 + i * 32 + rl, col = col0 + ch * 8;
-                            if (row < p.M && col < p.N)
-                                *reinterpret_cast<uint4*>(p.out_bf16 + (size_t)row * p.ldo + col) = v;
+                            if (row < p.M && col < p.N) {
+                                u32x4* dst = reinterpret_cast<u32x4*>(p.out_bf16 + (size_t)row * p.ldo + col);
+                                if constexpr (EPI == EPI_QKV) *dst = v;      // attention re-reads q|k from L2
+                                else TLD_STORE(dst, v);
+                            }
                         }
                     }
                 } else {
@@ -468,12 +471,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             for (int itr = 0; itr < 4; ++itr) {
                                 const int idx = itr * 64 + lane;
                                 const int f = idx >> 3, ch = idx & 7;
-                                const uint4 v = *reinterpret_cast<const uint4*>(ws + f * P + ch * 16);
+                                const u32x4 v = *reinterpret_cast<const u32x4*>(ws + f * P + ch * 16);
                                 const int row = row0 + half * 64 + ch * 8;
                                 const int fg = j * 32 + f;
                                 if (row < p.M && col0 + fg < p.N) {
                                     const int b = row / p.ntok, tk = row - b * p.ntok;
-                                    *reinterpret_cast<uint4*>(p.vt + ((size_t)b * p.d + cbase + fg) * p.ntok + tk) = v;
+                                    *reinterpret_cast<u32x4*>(p.vt + ((size_t)b * p.d + cbase + fg) * p.ntok + tk) = v;
                                 }
                             }
                         }
