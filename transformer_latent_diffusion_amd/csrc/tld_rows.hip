@@ -10,6 +10,7 @@
 // Row layout: a wave owns one token row of d features; lane l holds features {2l, 2l+1} + 128*j
 // (float2 per access, 512 B per wave-instruction), so d must be a multiple of 128.
 #include "tld_common.h"
+#include <cstdlib>
 
 namespace tld {
 
@@ -121,6 +122,45 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const resid_t* __re
         o[0] = (bf16)(v[j].x * rstd * gg.x + bb.x);
         o[1] = (bf16)(v[j].y * rstd * gg.y + bb.y);
         *reinterpret_cast<bf16x2*>(out + (size_t)row * d + n) = o;
+    }
+}
+
+// d % 256 == 0 form: lane l holds features {4l .. 4l+3} + 256 j, i.e. 8-byte loads of the bf16 residual and 8-byte
+// stores (the 2-feature layout above moves 4 bytes per lane and instruction)
+template <int NQ>
+__global__ __launch_bounds__(256) void layernorm_bf16_q4_kernel(const resid_t* __restrict__ x,
+                                                                const float* __restrict__ g,
+                                                                const float* __restrict__ b,
+                                                                bf16* __restrict__ out, int M, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float4 v[NQ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        v[j] = rs_load4(x + (size_t)row * d + j * 256 + 4 * lane);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+        q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int n = j * 256 + 4 * lane;
+        const float4 gg = *reinterpret_cast<const float4*>(g + n);
+        const float4 bb = *reinterpret_cast<const float4*>(b + n);
+        bf16x4 o;
+        o[0] = (bf16)(v[j].x * rstd * gg.x + bb.x);
+        o[1] = (bf16)(v[j].y * rstd * gg.y + bb.y);
+        o[2] = (bf16)(v[j].z * rstd * gg.z + bb.z);
+        o[3] = (bf16)(v[j].w * rstd * gg.w + bb.w);
+        *reinterpret_cast<bf16x4*>(out + (size_t)row * d + n) = o;
     }
 }
 
@@ -305,6 +345,185 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
                 o[0] = (bf16)r[0];
                 o[1] = (bf16)r[1];
                 *reinterpret_cast<bf16x2*>(p.xn3 + (row + u) * d + n) = o;
+            }
+        }
+    }
+}
+
+// d % 256 == 0 form of the kernel above: lane l holds features {4l .. 4l+3} + 256 j (8-byte loads and stores of the
+// bf16 streams instead of 4-byte ones; LayerNorm measured 20 -> 18 us from that alone).  The features of group j
+// in lane l belong to head 4j + (l >> 4), so the four logit sums of a head quartet are finished with two
+// v_permlane32_swap, one v_permlane16_swap and one 16-lane DPP reduction: row q of the wave ends with head 4j+q.
+template <int NQ>
+__global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, int chunks_per_sample) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int d = NQ * 256, H = NQ * 4;
+    constexpr float inv_d = 1.0f / (float)d;
+    float* wd = reinterpret_cast<float*>(smem);          // [H][d]  wq_label - wq_noise (gamma folded)
+    float* vn = wd + H * d;                              // [d]     value row of the noise token
+    float* vdiff = vn + d;                               // [d]     v_label - v_noise
+    float* bw = vdiff + d;                               // [H]     beta contribution to the logit diff
+
+    const int b = blockIdx.x / chunks_per_sample;
+    const int ck = blockIdx.x - b * chunks_per_sample;
+    const int pairs = p.ntok >> 1;
+    const int pp0 = (int)((long)ck * pairs / chunks_per_sample);
+    const int pp1 = (int)((long)(ck + 1) * pairs / chunks_per_sample);
+    const int tn = p.noise_row[b], tl = p.label_row[b];
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const resid_t* xin = p.x_in ? p.x_in : p.x;
+    const size_t obase = (size_t)b * p.ntok;
+    const size_t ibase = p.x_in ? (size_t)(b % p.src_batch) * p.ntok : obase;
+
+    float4 xr[2][NQ];
+    bf16x4 ar[2][NQ];
+    auto fetch = [&](size_t row, float4 (&xv)[NQ], bf16x4 (&av)[NQ]) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int n = j * 256 + 4 * lane;
+            xv[j] = rs_load4(xin + row * d + n);
+            av[j] = *reinterpret_cast<const bf16x4*>(p.att + row * d + n);
+        }
+    };
+    int pr = pp0 + wid;
+    if (pr < pp1) {
+        fetch(ibase + 2 * (size_t)pr, xr[0], ar[0]);
+        fetch(ibase + 2 * (size_t)pr + 1, xr[1], ar[1]);
+    }
+    {
+        const float4* wl = reinterpret_cast<const float4*>(p.wq + (size_t)tl * H * d);
+        const float4* wn = reinterpret_cast<const float4*>(p.wq + (size_t)tn * H * d);
+        float4* dst = reinterpret_cast<float4*>(wd);
+        for (int i = threadIdx.x; i < H * d / 4; i += 256) {
+            const float4 a = wl[i], c = wn[i];
+            dst[i] = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
+        }
+    }
+    for (int i = threadIdx.x; i < d; i += 256) {
+        const float a = p.v[(size_t)tn * p.v_ld + i];
+        vn[i] = a;
+        vdiff[i] = p.v[(size_t)tl * p.v_ld + i] - a;
+    }
+    if (threadIdx.x < H) bw[threadIdx.x] = p.bwq[(size_t)tl * H + threadIdx.x] - p.bwq[(size_t)tn * H + threadIdx.x];
+    __syncthreads();
+    float bwl[NQ];
+#pragma unroll
+    for (int hg = 0; hg < NQ; ++hg) bwl[hg] = bw[4 * hg + (lane >> 4)];
+
+    for (; pr < pp1; pr += 4) {
+        f32x4 v[2][NQ];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                v[u][j][0] = xr[u][j].x + (float)ar[u][j][0];        // x = SA(LN1 x) + x
+                v[u][j][1] = xr[u][j].y + (float)ar[u][j][1];
+                v[u][j][2] = xr[u][j].z + (float)ar[u][j][2];
+                v[u][j][3] = xr[u][j].w + (float)ar[u][j][3];
+            }
+        const size_t row = obase + 2 * (size_t)pr;
+        if (pr + 4 < pp1) {
+            fetch(ibase + 2 * (size_t)(pr + 4), xr[0], ar[0]);
+            fetch(ibase + 2 * (size_t)(pr + 4) + 1, xr[1], ar[1]);
+        }
+        if (p.sa_out) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < NQ; ++j)
+                    *reinterpret_cast<f32x4*>(p.sa_out + (row + u) * d + j * 256 + 4 * lane) = v[u][j];
+        }
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 s4 = v[u][0];
+#pragma unroll
+            for (int j = 1; j < NQ; ++j) s4 += v[u][j];
+            mean[u] = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_d;
+        }
+        f32x4 c[2][NQ];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                c[u][j] = v[u][j] - mean[u];
+                q4 = __builtin_elementwise_fma(c[u][j], c[u][j], q4);
+            }
+            rstd[u] = __builtin_amdgcn_rsqf(fmaf(wave_sum((q4[0] + q4[1]) + (q4[2] + q4[3])), inv_d, kLnEps));
+        }
+
+        float plab[2][NQ];
+#pragma unroll
+        for (int hg = 0; hg < NQ; ++hg) {
+            float part[2][4];
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) {
+                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                const float* w0 = wd + (4 * hg + hh) * d + 4 * lane;
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(w0 + j * 256);
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[u] = __builtin_elementwise_fma(c[u][j], a, acc[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) part[u][hh] = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[u][0]), __float_as_uint(part[u][2]), false, false);
+                const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[u][1]), __float_as_uint(part[u][3]), false, false);
+                const float a02 = __uint_as_float(s02[0]) + __uint_as_float(s02[1]);      // lanes 0-31: head 0, 32-63: head 2
+                const float a13 = __uint_as_float(s13[0]) + __uint_as_float(s13[1]);      // lanes 0-31: head 1, 32-63: head 3
+                const auto sr = __builtin_amdgcn_permlane16_swap(__float_as_uint(a02), __float_as_uint(a13), false, false);
+                float t = __uint_as_float(sr[0]) + __uint_as_float(sr[1]);                // wave row q: head q
+                t = dpp_add<0xB1>(t); t = dpp_add<0x4E>(t); t = dpp_add<0x141>(t); t = dpp_add<0x140>(t);
+                const float dl = t * rstd[u] + bwl[hg];
+                plab[u][hg] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-dl * 1.44269504088896340736f));
+            }
+            __builtin_amdgcn_sched_barrier(0);     // keep the next head quartet's LDS reads from being hoisted (VGPRs)
+        }
+        // x += p_noise v_n + p_label v_l ; then LN3
+        float mean3[2], rstd3[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const int n = j * 256 + 4 * lane;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(vn + n);
+                const f32x4 dd = *reinterpret_cast<const f32x4*>(vdiff + n);
+                const f32x4 pl = {plab[u][j], plab[u][j], plab[u][j], plab[u][j]};
+                v[u][j] += __builtin_elementwise_fma(pl, dd, a);
+                rs_store4(p.x + (row + u) * d + n, make_float4(v[u][j][0], v[u][j][1], v[u][j][2], v[u][j][3]));
+                s4 += v[u][j];
+            }
+            mean3[u] = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_d;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                v[u][j] -= mean3[u];
+                q4 = __builtin_elementwise_fma(v[u][j], v[u][j], q4);
+            }
+            rstd3[u] = __builtin_amdgcn_rsqf(fmaf(wave_sum((q4[0] + q4[1]) + (q4[2] + q4[3])), inv_d, kLnEps));
+        }
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const int n = j * 256 + 4 * lane;
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(p.ln3_w + n);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln3_b + n);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 r = __builtin_elementwise_fma(v[u][j] * rstd3[u], gg, bb);
+                bf16x4 o;
+                o[0] = (bf16)r[0]; o[1] = (bf16)r[1]; o[2] = (bf16)r[2]; o[3] = (bf16)r[3];
+                *reinterpret_cast<bf16x4*>(p.xn3 + (row + u) * d + n) = o;
             }
         }
     }
@@ -556,6 +775,11 @@ void launch_embed(const EmbedParams& p, hipStream_t s) {
 
 void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf16* out, int M, int d,
                            hipStream_t s) {
+    static const bool q4 = !(getenv("TLD_LN_Q4") && atoi(getenv("TLD_LN_Q4")) == 0);      // A/B knob
+    if (q4 && d == 768) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
+    if (q4 && d == 512) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
+    if (q4 && d == 256) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
+    if (q4 && d == 1024) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
     TLD_DISPATCH_NJ(d / 128, hipLaunchKernelGGL(layernorm_bf16_kernel<NJ>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d));
 }
 
@@ -577,6 +801,10 @@ void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
     if (cps < 1) cps = 1;
     const int lds = (p.heads * p.d + 2 * p.d + p.heads) * (int)sizeof(float);
     dim3 grid((unsigned)(p.batch * cps));
+    static const bool q4 = !(getenv("TLD_CROSS_Q4") && atoi(getenv("TLD_CROSS_Q4")) == 0);      // A/B knob
+    if (q4 && p.d == 768) { hipLaunchKernelGGL(cross_row_q4_kernel<3>, grid, dim3(256), lds, s, p, (int)cps); return; }
+    if (q4 && p.d == 512) { hipLaunchKernelGGL(cross_row_q4_kernel<2>, grid, dim3(256), lds, s, p, (int)cps); return; }
+    if (q4 && p.d == 256) { hipLaunchKernelGGL(cross_row_q4_kernel<1>, grid, dim3(256), lds, s, p, (int)cps); return; }
     TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(cross_row_kernel<NJ>, grid, dim3(256), lds, s, p, (int)cps));
 }
 
