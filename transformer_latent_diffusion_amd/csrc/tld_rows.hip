@@ -18,15 +18,20 @@ namespace {
 
 
 // ------------------------------------------------------------------------------------------------
-// Workgroup = 64 token rows (16 per wave); the Linear(pd -> d) weight table [pd][d] fp32 (49 KB at d = 768)
+// Workgroup = 32 token rows (8 per wave); the Linear(pd -> d) weight table [pd][d] fp32 (49 KB at d = 768)
 // is staged in LDS once per workgroup -- read per row from L1/L2 it made the kernel L1-bandwidth bound.
 template <int NJ>
 __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int d = NJ * 128;
     float* wt = reinterpret_cast<float*>(smem);                  // [pd][d]
+    float* cwt = wt + p.pd * d;                                  // [C p p][pd]  conv weight, transposed (lane = output)
     for (int i = threadIdx.x; i < p.pd * d / 4; i += 256)
         reinterpret_cast<float4*>(wt)[i] = reinterpret_cast<const float4*>(p.lin_wt)[i];
+    for (int i = threadIdx.x; i < p.pd * p.C * p.p * p.p; i += 256) {
+        const int o = i / (p.C * p.p * p.p), k = i - o * (p.C * p.p * p.p);
+        cwt[k * p.pd + o] = p.conv_w[i];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -34,22 +39,43 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
     const int total = p.batch * p.ntok;
     // per-lane constants
     const float cb = lane < p.pd ? p.conv_b[lane] : 0.f;
-    const float* cw = p.conv_w + (lane < p.pd ? lane : 0) * cpp;
+    const float* cw = cwt + (lane < p.pd ? lane : 0);            // + i * pd
     const float g1 = lane < p.pd ? p.ln1_w[lane] : 0.f, b1 = lane < p.pd ? p.ln1_b[lane] : 0.f;
     const int ic = lane / pp, iuv = lane - ic * pp, iu = iuv / p.p, iv = iuv - iu * p.p;   // lane = (c,u,v) for loads
-    constexpr int ROWS_PER_WAVE = 16;
+    // 8 rows per wave, two workgroups per CU at the bench size: with 16 rows per wave and one workgroup per CU the
+    // kernel was bound by the latency of each row's input load (90 us for 16 K rows); the next row's load is issued early
+    constexpr int ROWS_PER_WAVE = 8;
+    auto load_in = [&](int row) {
+        float xv = 0.f;
+        if (row < total && lane < cpp) {
+            const int b = row / p.ntok, t = row - b * p.ntok;
+            const int ti = t / p.grid, tj = t - ti * p.grid;
+            xv = p.x[(((size_t)(b % p.src_batch) * p.C + ic) * p.S + (ti * p.p + iu)) * p.S + (tj * p.p + iv)];
+        }
+        return xv;
+    };
+    const int row_first = (blockIdx.x * 4 + wid) * ROWS_PER_WAVE;
+    float xnext = load_in(row_first);
     for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-        const int row = (blockIdx.x * 4 + wid) * ROWS_PER_WAVE + rr;
+        const int row = row_first + rr;
         if (row >= total) return;
-        const int b = row / p.ntok, t = row - b * p.ntok;
-        const int ti = t / p.grid, tj = t - ti * p.grid;
-        float xin = 0.f;
-        if (lane < cpp)
-            xin = p.x[(((size_t)(b % p.src_batch) * p.C + ic) * p.S + (ti * p.p + iu)) * p.S + (tj * p.p + iv)];
+        const int t = row % p.ntok;
+        const float xin = xnext;
+        if (rr + 1 < ROWS_PER_WAVE) xnext = load_in(row + 1);
+        // (both small loops are unrolled by hand -- `#pragma unroll` refuses loops around v_readlane -- so that the
+        // LDS reads of four taps are in flight together; they were one exposed LDS latency per tap)
         float pv = cb;
-        for (int i = 0; i < cpp; ++i) {
-            const float xv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xin), i));
-            pv = fmaf(cw[i], xv, pv);
+        {
+            int i = 0;
+            for (; i + 4 <= cpp; i += 4) {
+                const float c0 = cw[(i + 0) * p.pd], c1 = cw[(i + 1) * p.pd], c2 = cw[(i + 2) * p.pd], c3 = cw[(i + 3) * p.pd];
+                pv = fmaf(c0, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xin), i + 0)), pv);
+                pv = fmaf(c1, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xin), i + 1)), pv);
+                pv = fmaf(c2, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xin), i + 2)), pv);
+                pv = fmaf(c3, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xin), i + 3)), pv);
+            }
+            for (; i < cpp; ++i)
+                pv = fmaf(cw[i * p.pd], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xin), i)), pv);
         }
         if (lane >= p.pd) pv = 0.f;
         const float inv_pd = 1.0f / (float)p.pd;
@@ -61,14 +87,24 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
         float2 e[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) e[j] = *reinterpret_cast<const float2*>(p.lin_b + j * 128 + 2 * lane);
-        for (int o = 0; o < p.pd; ++o) {
+        auto lin_tap = [&](int o, const float2 (&w)[NJ]) {
             const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pn), o));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { e[j].x = fmaf(a, w[j].x, e[j].x); e[j].y = fmaf(a, w[j].y, e[j].y); }
+        };
+        auto lin_load = [&](int o, float2 (&w)[NJ]) {
             const float* wrow = wt + o * d + 2 * lane;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const float2 w = *reinterpret_cast<const float2*>(wrow + j * 128);
-                e[j].x = fmaf(a, w.x, e[j].x); e[j].y = fmaf(a, w.y, e[j].y);
+            for (int j = 0; j < NJ; ++j) w[j] = *reinterpret_cast<const float2*>(wrow + j * 128);
+        };
+        {
+            int o = 0;
+            for (; o + 2 <= p.pd; o += 2) {
+                float2 w0[NJ], w1[NJ];
+                lin_load(o, w0); lin_load(o + 1, w1);
+                lin_tap(o, w0); lin_tap(o + 1, w1);
             }
+            if (o < p.pd) { float2 w0[NJ]; lin_load(o, w0); lin_tap(o, w0); }
         }
         float s = 0.f;
 #pragma unroll
@@ -769,8 +805,8 @@ __global__ __launch_bounds__(256) void dwconv_gelu_tiled_kernel(const bf16* __re
 
 void launch_embed(const EmbedParams& p, hipStream_t s) {
     const int rows = p.batch * p.ntok;
-    const int lds = p.pd * p.d * (int)sizeof(float);
-    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(embed_kernel<NJ>, dim3((rows + 63) / 64), dim3(256), lds, s, p));
+    const int lds = (p.pd * p.d + p.pd * p.C * p.p * p.p) * (int)sizeof(float);
+    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(embed_kernel<NJ>, dim3((rows + 31) / 32), dim3(256), lds, s, p));
 }
 
 void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf16* out, int M, int d,
