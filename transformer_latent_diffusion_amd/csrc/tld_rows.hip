@@ -576,17 +576,30 @@ __global__ __launch_bounds__(256) void tail_kernel(TailParams p, int rows_per_bl
         reinterpret_cast<float4*>(w)[i] = reinterpret_cast<const float4*>(p.w)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int rows_per_wave = rows_per_block / 4;
-    const int total = p.batch * p.ntok;
-    for (int rr = 0; rr < rows_per_wave; ++rr) {
-        const int row = blockIdx.x * rows_per_block + wid * rows_per_wave + rr;
-        if (row >= total) return;
-        float2 v[NJ];
+    const int rows_per_wave = rows_per_block / 4;            // even
+    const int total = p.batch * p.ntok;                      // even (ntok is)
+    const int row_first = blockIdx.x * rows_per_block + wid * rows_per_wave;
+    // two rows at a time (eight independent dot-product / reduction chains), the next pair's loads issued first
+    float2 nx[2][NJ];
+    auto fetch = [&](int row, float2 (&v)[NJ]) {
+        const int r = row < total ? row : total - 1;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) v[j] = rs_load2(p.tok + (size_t)row * d + j * 128 + 2 * lane);
-        float mine = 0.f;
-        for (int o4 = 0; o4 < p.pd; o4 += 4) {              // four independent dot-product / reduction chains
-            float part[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) v[j] = rs_load2(p.tok + (size_t)r * d + j * 128 + 2 * lane);
+    };
+    fetch(row_first, nx[0]); fetch(row_first + 1, nx[1]);
+    const float bias = p.b[lane < p.pd ? lane : 0];
+    for (int rr = 0; rr < rows_per_wave; rr += 2) {
+        const int row = row_first + rr;
+        if (row >= total) return;
+        float2 v[2][NJ];
+#pragma unroll
+        for (int u2 = 0; u2 < 2; ++u2)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) v[u2][j] = nx[u2][j];
+        if (rr + 2 < rows_per_wave) { fetch(row + 2, nx[0]); fetch(row + 3, nx[1]); }
+        float mine[2] = {0.f, 0.f};
+        for (int o4 = 0; o4 < p.pd; o4 += 4) {
+            float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int o = o4 + u < p.pd ? o4 + u : p.pd - 1;
@@ -594,22 +607,32 @@ __global__ __launch_bounds__(256) void tail_kernel(TailParams p, int rows_per_bl
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const float2 ww = *reinterpret_cast<const float2*>(wrow + j * 128);
-                    part[u] = fmaf(v[j].x, ww.x, fmaf(v[j].y, ww.y, part[u]));
+#pragma unroll
+                    for (int u2 = 0; u2 < 2; ++u2)
+                        part[u2][u] = fmaf(v[u2][j].x, ww.x, fmaf(v[u2][j].y, ww.y, part[u2][u]));
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float tot = wave_sum(part[u]);
-                if (lane == o4 + u) mine = tot + p.b[lane < p.pd ? lane : 0];
-            }
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int u2 = 0; u2 < 2; ++u2) {
+                    const float tot = wave_sum(part[u2][u]);
+                    if (lane == o4 + u) mine[u2] = tot + bias;
+                }
         }
         if (lane < p.pd) {
             // feature f = (c, u, v) of token (ti, tj) -> out[b, c, ti*p+u, tj*p+v]
-            const int b = row / p.ntok, t = row - b * p.ntok;
-            const int ti = t / p.grid, tj = t - ti * p.grid;
             const int c = lane / (p.p * p.p), uv = lane - c * p.p * p.p;
             const int u = uv / p.p, vv = uv - u * p.p;
-            p.out[(((size_t)b * p.C + c) * p.S + (ti * p.p + u)) * p.S + (tj * p.p + vv)] = mine;
+#pragma unroll
+            for (int u2 = 0; u2 < 2; ++u2) {
+                const int r = row + u2;
+                if (r < total) {
+                    const int b = r / p.ntok, t = r - b * p.ntok;
+                    const int ti = t / p.grid, tj = t - ti * p.grid;
+                    p.out[(((size_t)b * p.C + c) * p.S + (ti * p.p + u)) * p.S + (tj * p.p + vv)] = mine[u2];
+                }
+            }
         }
     }
 }
