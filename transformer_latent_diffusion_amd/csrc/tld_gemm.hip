@@ -98,9 +98,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     const int bid = blockIdx.x;
     const int xcd = bid & 7, lidx = bid >> 3;
     const int per_xcd_blocks = (nblocks + 7 - xcd) / 8;               // blocks with this xcd id
+    // default: the tile order is row-major (n fastest) and XCD x owns a contiguous 1/8 of it.
+    // xcd_ngroups = G > 1: the XCDs form an (8/G) x G grid; XCD (xm, xn) owns tile-rows block xm and the tile-column
+    // group xn, walked row-major inside.  Its W working set shrinks to ntn/G tiles (resident in the 4 MB L2 across
+    // rounds) at the price of every A tile being fetched by G XCDs.
+    const int G2 = p.xcd_ngroups > 1 ? p.xcd_ngroups : 1;
+    const int xn = xcd % G2, xm = xcd / G2, XM = 8 / G2;
+    const int gcols = ntn / G2;                                        // tile-columns per group (ntn % G2 == 0)
+    const int r0 = (int)((long)ntm * xm / XM), r1 = (int)((long)ntm * (xm + 1) / XM);
     const int q = ntiles >> 3, rr = ntiles & 7;
     const int xbase = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
-    const int xcount = q + (xcd < rr ? 1 : 0);
+    const int xcount = G2 > 1 ? (r1 - r0) * gcols : q + (xcd < rr ? 1 : 0);
     const int my_tiles = lidx < xcount ? (xcount - lidx + per_xcd_blocks - 1) / per_xcd_blocks : 0;
     auto tile_coords = [&](int i, int& m0, int& n0) {
         // Row-major over tiles (n fastest), and XCD x owns a contiguous run of it: the ~32 workgroups of an XCD then
@@ -108,10 +116,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         // serves every column while it is hot, and the W tiles are re-used by every round.  (The earlier order --
         // super-rows of 8 tile-rows, m fastest -- revisited each A super-row once per group of 4 columns, a full
         // round apart: PMC L2-miss traffic 381 MB vs 204 MB algorithmic on the QKV GEMM; this order: 134 -> 111 us.)
-        const int tile = xbase + lidx + i * per_xcd_blocks;
-        const int tm = tile / ntn;
-        m0 = tm * G::BM;
-        n0 = (tile - tm * ntn) * BN;
+        const int t = lidx + i * per_xcd_blocks;
+        if (G2 > 1) {
+            const int tm = t / gcols;
+            m0 = (r0 + tm) * G::BM;
+            n0 = (xn * gcols + (t - tm * gcols)) * BN;
+        } else {
+            const int tile = xbase + t;
+            const int tm = tile / ntn;
+            m0 = tm * G::BM;
+            n0 = (tile - tm * ntn) * BN;
+        }
     };
     if (my_tiles == 0) return;
 
@@ -500,6 +515,14 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     }
     const int nblocks = ntm * ntn < ncu ? ntm * ntn : ncu;
     dim3 grid(nblocks), block(512);
+    // Up-projection (12 tile-columns at d = 768): two column groups x four tile-row blocks over the 8 XCDs keep each
+    // XCD's W working set at 2.4 MB (L2-resident across rounds; it was re-fetched every round, PMC fetch 296 MB vs
+    // 55 MB algorithmic) while A is fetched by two XCDs instead of one: 235 -> 228 us.  Measured and rejected:
+    // four groups for the up-projection (neutral), two / four groups for the down-projection (A is the 201 MB
+    // operand there: neutral / 175 -> 195 us).  Large launches only: every XCD cell needs workgroups of its own.
+    GemmParams pg = p;
+    if ((epilogue == EPI_UP_DWCONV || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
+        pg.xcd_ngroups = 2;
 #define TLD_L256P(E)                                                                                  \
     do {                                                                                              \
         static bool once = false;                                                                     \
@@ -508,7 +531,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);            \
             once = true;                                                                              \
         }                                                                                             \
-        hipLaunchKernelGGL((gemm256p_kernel<BN, E>), grid, block, G::LDS_BYTES, s, p, nblocks);       \
+        hipLaunchKernelGGL((gemm256p_kernel<BN, E>), grid, block, G::LDS_BYTES, s, pg, nblocks);      \
     } while (0)
     if constexpr (BN == 192) {
         TLD_L256P(EPI_BIAS_RESID);
