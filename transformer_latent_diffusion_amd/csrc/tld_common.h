@@ -264,8 +264,11 @@ void launch_sinusoid(const float* sigma, const float* angular, float* out, int T
 void launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int M, int d,
                           hipStream_t s);
 // raw[t,h,j] = (1/8) sum_c k[t, h*64+c] Wq[h*64+c, j];  wq = raw * gamma[j];  bwq[t,h] = sum_j beta[j] raw
-void launch_wq(const float* k, int ldk, const float* Wq, const float* gamma, const float* beta, float* wq,
-               float* bwq, int T, int heads, int d, hipStream_t s);
+void launch_linear_f32_layers(const float* in, int ldi, const float* const* Wl, float* out, size_t out_lstride,
+                              int ldo, int T, int K, int N, int layers, hipStream_t s);
+void launch_wq_layers(const float* k, size_t k_lstride, int ldk, const float* const* Wql, const float* const* gammal,
+                      const float* const* betal, float* wq, size_t wq_lstride, float* bwq, size_t bwq_lstride, int T,
+                      int heads, int d, int layers, hipStream_t s);
 // dst_f32 <- src (fp32/bf16/f16) and back
 void launch_cast_to_f32(const void* src, int dtype, float* dst, int64_t n, hipStream_t s);
 void launch_cast_from_f32(const float* src, void* dst, int dtype, int64_t n, hipStream_t s);

@@ -29,11 +29,14 @@ __global__ void sinusoid_kernel(const float* __restrict__ sigma, const float* __
 
 // block: 8 token rows x 64 output columns; 4 waves, each wave 16 columns; lanes stride over K.
 constexpr int LR = 8;
+// blockIdx.z = layer for the batched launches: W then comes from the pointer table Wl and out advances by out_lstride
 __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ in, int ldi,
                                                          const float* __restrict__ W,
+                                                         const float* const* __restrict__ Wl,
                                                          const float* __restrict__ bias,
-                                                         float* __restrict__ out, int ldo, int T, int K,
-                                                         int N, int act) {
+                                                         float* __restrict__ out, size_t out_lstride, int ldo, int T,
+                                                         int K, int N, int act) {
+    if (Wl) { W = Wl[blockIdx.z]; out += (size_t)blockIdx.z * out_lstride; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xs = reinterpret_cast<float*>(smem);          // [LR][K]
     const int t0 = blockIdx.y * LR;
@@ -90,11 +93,17 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restr
 }
 
 // grid (heads, ceil(T/8)); thread j strides over d; k rows (64 features of this head) in LDS.
-__global__ __launch_bounds__(256) void wq_kernel(const float* __restrict__ kmat, int ldk,
-                                                 const float* __restrict__ Wq,
-                                                 const float* __restrict__ gamma,
-                                                 const float* __restrict__ beta, float* __restrict__ wq,
-                                                 float* __restrict__ bwq, int T, int H, int d) {
+// blockIdx.z = layer: per-layer pointers from tables (Wq, gamma, beta), strided inputs / outputs
+__global__ __launch_bounds__(256) void wq_kernel(const float* __restrict__ kmat, size_t k_lstride, int ldk,
+                                                 const float* const* __restrict__ Wql,
+                                                 const float* const* __restrict__ gammal,
+                                                 const float* const* __restrict__ betal, float* __restrict__ wq,
+                                                 size_t wq_lstride, float* __restrict__ bwq, size_t bwq_lstride, int T,
+                                                 int H, int d) {
+    const float* __restrict__ Wq = Wql[blockIdx.z];
+    const float* __restrict__ gamma = gammal[blockIdx.z];
+    const float* __restrict__ beta = betal[blockIdx.z];
+    kmat += (size_t)blockIdx.z * k_lstride; wq += (size_t)blockIdx.z * wq_lstride; bwq += (size_t)blockIdx.z * bwq_lstride;
     __shared__ float ks[LR][64];
     __shared__ float red[4][LR];
     const int h = blockIdx.x, t0 = blockIdx.y * LR;
@@ -171,8 +180,16 @@ void launch_sinusoid(const float* sigma, const float* angular, float* out, int T
 void launch_linear_f32(const float* in, int ldi, const float* W, const float* b, float* out, int ldo, int T,
                        int K, int N, int act, hipStream_t s) {
     dim3 grid((N + 63) / 64, (T + LR - 1) / LR);
-    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), LR * K * sizeof(float), s, in, ldi, W, b, out, ldo,
-                       T, K, N, act);
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), LR * K * sizeof(float), s, in, ldi, W,
+                       (const float* const*)nullptr, b, out, (size_t)0, ldo, T, K, N, act);
+}
+
+// the same input rows through `layers` weight matrices in one launch: out[l] = in . W[l]^T (no bias)
+void launch_linear_f32_layers(const float* in, int ldi, const float* const* Wl, float* out, size_t out_lstride,
+                              int ldo, int T, int K, int N, int layers, hipStream_t s) {
+    dim3 grid((N + 63) / 64, (T + LR - 1) / LR, layers);
+    hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), LR * K * sizeof(float), s, in, ldi, (const float*)nullptr,
+                       Wl, (const float*)nullptr, out, out_lstride, ldo, T, K, N, 0);
 }
 
 void launch_layernorm_f32(const float* x, const float* g, const float* b, float* out, int M, int d,
@@ -180,10 +197,12 @@ void launch_layernorm_f32(const float* x, const float* g, const float* b, float*
     hipLaunchKernelGGL(layernorm_f32_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d);
 }
 
-void launch_wq(const float* k, int ldk, const float* Wq, const float* gamma, const float* beta, float* wq,
-               float* bwq, int T, int heads, int d, hipStream_t s) {
-    dim3 grid(heads, (T + LR - 1) / LR);
-    hipLaunchKernelGGL(wq_kernel, grid, dim3(256), 0, s, k, ldk, Wq, gamma, beta, wq, bwq, T, heads, d);
+void launch_wq_layers(const float* k, size_t k_lstride, int ldk, const float* const* Wql, const float* const* gammal,
+                      const float* const* betal, float* wq, size_t wq_lstride, float* bwq, size_t bwq_lstride, int T,
+                      int heads, int d, int layers, hipStream_t s) {
+    dim3 grid(heads, (T + LR - 1) / LR, layers);
+    hipLaunchKernelGGL(wq_kernel, grid, dim3(256), 0, s, k, k_lstride, ldk, Wql, gammal, betal, wq, wq_lstride, bwq,
+                       bwq_lstride, T, heads, d);
 }
 
 void launch_iota(int* dst, int n, int base, hipStream_t s) {

@@ -78,6 +78,7 @@ struct tld_engine {
           *plin_b = nullptr, *pln2_w = nullptr, *pln2_b = nullptr, *pos = nullptr, *out_w = nullptr,
           *out_b = nullptr;
     std::vector<Layer> layers;
+    const float **tab_kv_w = nullptr, **tab_q_w = nullptr, **tab_n2_w = nullptr, **tab_n2_b = nullptr;   // [L] device tables
 
     // activations (sized for cfg.max_batch)
     resid_t* x = nullptr;
@@ -198,13 +199,11 @@ int cond_tables(tld_engine* e, int T, hipStream_t s) {
     const int d = e->d;
     ProfScope ps(e, KC_COND, s);
     launch_layernorm_f32(e->c_pre, e->norm_w, e->norm_b, e->c_y, T, d, s);
-    for (int l = 0; l < e->L; ++l) {
-        const Layer& Ly = e->layers[l];
-        float* kv = e->c_kv + (size_t)l * e->cond_cap * 2 * d;
-        launch_linear_f32(e->c_y, d, Ly.kv_w, nullptr, kv, 2 * d, T, d, 2 * d, 0, s);
-        launch_wq(kv, 2 * d, Ly.q_w, Ly.n2_w, Ly.n2_b, e->c_wq + (size_t)l * e->cond_cap * e->H * d,
-                  e->c_bwq + (size_t)l * e->cond_cap * e->H, T, e->H, d, s);
-    }
+    // all layers in two launches (blockIdx.z = layer; per-layer weights through pointer tables): these are small
+    // fp32 problems (T ~ 100 token rows), 24 dependent launches of them were 2 ms per generate
+    launch_linear_f32_layers(e->c_y, d, e->tab_kv_w, e->c_kv, (size_t)e->cond_cap * 2 * d, 2 * d, T, d, 2 * d, e->L, s);
+    launch_wq_layers(e->c_kv, (size_t)e->cond_cap * 2 * d, 2 * d, e->tab_q_w, e->tab_n2_w, e->tab_n2_b, e->c_wq,
+                     (size_t)e->cond_cap * e->H * d, e->c_bwq, (size_t)e->cond_cap * e->H, T, e->H, d, e->L, s);
     return TLD_OK;
 }
 
@@ -458,6 +457,18 @@ int tld_engine_finalize_weights(tld_engine* e) {
 #undef LK
     }
     e->host.clear();
+    {   // per-layer pointer tables for the layer-batched conditioning launches
+        const size_t L = (size_t)e->L;
+        std::vector<const float*> hk(L), hq(L), hg(L), hb(L);
+        for (size_t l = 0; l < L; ++l) { hk[l] = e->layers[l].kv_w; hq[l] = e->layers[l].q_w; hg[l] = e->layers[l].n2_w; hb[l] = e->layers[l].n2_b; }
+        const float** tabs = nullptr;
+        if (int rc = dev_alloc(e, &tabs, 4 * L)) return rc;
+        e->tab_kv_w = tabs; e->tab_q_w = tabs + L; e->tab_n2_w = tabs + 2 * L; e->tab_n2_b = tabs + 3 * L;
+        HIP_TRY(hipMemcpy(e->tab_kv_w, hk.data(), L * sizeof(float*), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->tab_q_w, hq.data(), L * sizeof(float*), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->tab_n2_w, hg.data(), L * sizeof(float*), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(e->tab_n2_b, hb.data(), L * sizeof(float*), hipMemcpyHostToDevice));
+    }
 
     const size_t B2 = (size_t)e->cfg.max_batch, M = B2 * e->ntok;
     if (int rc = dev_alloc(e, &e->x, M * d)) return rc;
