@@ -42,11 +42,12 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds_tile, int row, int k
 // row per K-step: a BK = 32 ring with 64-B row segments measured no faster than a 128x128 kernel), 8 waves,
 // two LDS stages.  Waves: BN=256 -> 2(M) x 4(N), wave tile 128 x 64 (4 x 2 MFMA tiles of 32x32);
 // BN=128 -> 4 x 2, 64 x 64;  BN=192 -> 4 x 2, 64 x 96 (residual-add epilogue only: N = 768 then fills
-// 256 CUs in exactly 2 rounds).
+// 256 CUs in exactly 2 rounds);  BN=384 -> 2 x 4, 128 x 96 (residual-add epilogue only, 192 accumulator registers
+// per lane, single-buffered fragments, all 160 KB of LDS: N = 768 at M = 32 K is ONE round of 256 workgroups).
 template <int BN>
 struct G256 {
     static constexpr int BM = 256, BK = 64;
-    static constexpr int WN = (BN == 256) ? 4 : 2, WMc = 8 / WN;   // waves along N / M
+    static constexpr int WN = (BN >= 256) ? 4 : 2, WMc = 8 / WN;   // waves along N / M
     static constexpr int WROWS = BM / WMc;                      // rows per wave: 128 or 64
     static constexpr int WCOLS = BN / WN;                       // cols per wave: 64 (BN 256/128) or 96 (BN 192)
     static constexpr int TM = WROWS / 32, TN = WCOLS / 32;      // 32x32 MFMA tiles per wave
@@ -245,6 +246,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         dma_piece(q2, pkb, nst);
                     }
                 };
+                if constexpr (BN == 384) {
+                    // 192 accumulator registers per lane: fragments are single-buffered (the SIMD's other wave covers
+                    // the LDS latency), nothing is deferred across the barrier
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        load_frags(st, ks, a0, b0);
+                        pieces((ks * NP + 3) / 4, ((ks + 1) * NP + 3) / 4);
+                        mma(a0, b0);
+                    }
+                    continue;
+                }
                 load_frags(st, 0, a0, b0);
                 if (k > 0) mma(a1, b1);            // deferred: k-slice 3 of the previous step (fragments already in registers)
                 pieces(0, (NP + 3) / 4);
@@ -262,7 +274,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // k-slice 3 fragments are in registers before the stage is released
                 stamp(k, 5);
             }
-            mma(a1, b1);                           // k-slice 3 of the tile's last step
+            if constexpr (BN != 384) mma(a1, b1);  // k-slice 3 of the tile's last step
         };
         if constexpr (EPI == EPI_QKV) {
             if (swapped) kloop(std::true_type{}); else kloop(std::false_type{});
@@ -429,6 +441,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         }
                     }
             } else if constexpr (G::WCOLS == 64) {
+                // lane-derived values re-materialised per tile: otherwise every address expression of this epilogue is
+                // hoisted out of the tile loop and lives (or spills) across the K loops
+                int e_lane = lane, e_l31 = l31, e_hi = hi;
+                asm volatile("" : "+v"(e_lane), "+v"(e_l31), "+v"(e_hi));
                 const bool to_vt = (EPI == EPI_QKV) && !swapped;
                 if (!to_vt) {
                     // one 32-row x 64-col bf16 slab per pass: 128-B pitch, 16-B chunks XOR-swizzled with (row & 7)
@@ -439,7 +455,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         for (int j = 0; j < G::TN; ++j)
 #pragma unroll
                             for (int rq = 0; rq < 4; ++rq) {
-                                const int cl = j * 32 + 8 * rq + 4 * hi;
+                                const int cl = j * 32 + 8 * rq + 4 * e_hi;
                                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
                                 if constexpr (EPI == EPI_BIAS_BF16) {
                                     const int cg = col0 + cl < p.N ? col0 + cl : 0;
@@ -450,11 +466,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                 pk[1] = (bf16)(acc[i][j][rq * 4 + 1] + bv.y);
                                 pk[2] = (bf16)(acc[i][j][rq * 4 + 2] + bv.z);
                                 pk[3] = (bf16)(acc[i][j][rq * 4 + 3] + bv.w);
-                                *reinterpret_cast<bf16x4*>(ws + l31 * P + ((((cl >> 3) ^ (l31 & 7)) << 4) | ((cl & 7) << 1))) = pk;
+                                *reinterpret_cast<bf16x4*>(ws + e_l31 * P + ((((cl >> 3) ^ (e_l31 & 7)) << 4) | ((cl & 7) << 1))) = pk;
                             }
 #pragma unroll
                         for (int itr = 0; itr < 4; ++itr) {
-                            const int idx = itr * 64 + lane;
+                            const int idx = itr * 64 + e_lane;
                             const int rl = idx >> 3, ch = idx & 7;
                             const u32x4 v = *reinterpret_cast<const u32x4*>(ws + rl * P + ((ch ^ (rl & 7)) << 4));
                             const int row = row0 + i * 32 + rl, col = col0 + ch * 8;
@@ -481,11 +497,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                     bf16x4 pk;
                                     pk[0] = (bf16)acc[i][j][rq * 4 + 0]; pk[1] = (bf16)acc[i][j][rq * 4 + 1];
                                     pk[2] = (bf16)acc[i][j][rq * 4 + 2]; pk[3] = (bf16)acc[i][j][rq * 4 + 3];
-                                    *reinterpret_cast<bf16x4*>(ws + l31 * P + (ii * 32 + 8 * rq + 4 * hi) * 2) = pk;
+                                    *reinterpret_cast<bf16x4*>(ws + e_l31 * P + (ii * 32 + 8 * rq + 4 * e_hi) * 2) = pk;
                                 }
 #pragma unroll
                             for (int itr = 0; itr < 4; ++itr) {
-                                const int idx = itr * 64 + lane;
+                                const int idx = itr * 64 + e_lane;
                                 const int f = idx >> 3, ch = idx & 7;
                                 const u32x4 v = *reinterpret_cast<const u32x4*>(ws + f * P + ch * 16);
                                 const int row = row0 + half * 64 + ch * 8;
@@ -533,7 +549,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
         }                                                                                             \
         hipLaunchKernelGGL((gemm256p_kernel<BN, E>), grid, block, G::LDS_BYTES, s, pg, nblocks);      \
     } while (0)
-    if constexpr (BN == 192) {
+    if constexpr (BN == 192 || BN == 384) {
         TLD_L256P(EPI_BIAS_RESID);
     } else {
         switch (epilogue) {
@@ -560,10 +576,14 @@ int choose_bn(long M, long N, int epilogue) {
     static const char* force = getenv("TLD_GEMM_BN");             // experiment knob
     int bn = narrow ? 128 : 256;
     if (narrow && epilogue == EPI_BIAS_RESID && N % 192 == 0 && (ntm * (N / 192)) % 256 == 0) bn = 192;
+    // down projection at the bench size: 256 x 384 tiles make N = 768 ONE round of 256 workgroups (176 -> 155 us)
+    static const bool wide = !(getenv("TLD_DOWN_BN384") && atoi(getenv("TLD_DOWN_BN384")) == 0);     // A/B knob
+    if (wide && epilogue == EPI_BIAS_RESID && N % 384 == 0 && (ntm * (N / 384)) % 256 == 0) bn = 384;
     if (force) bn = atoi(force);
     if (epilogue == EPI_UP_DWCONV) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
     if (bn == 192 && (epilogue != EPI_BIAS_RESID || N % 192)) bn = 128;
-    if (bn != 256 && bn != 192) bn = 128;
+    if (bn == 384 && (epilogue != EPI_BIAS_RESID || N % 384)) bn = 128;
+    if (bn != 256 && bn != 192 && bn != 384) bn = 128;
     return bn;
 }
 }  // namespace
@@ -580,7 +600,8 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
     // (A column-split QKV launch -- 8 tile-columns of 256 as 4 whole rounds + the 9th as 128-wide tiles -- was
     // measured: 109.8 + 27.8 us vs 134 us for the single 4.5-round launch; a one-round launch pays ~12 us of
     // ramp/drain, so the half-empty fifth round is the cheaper tail.)
-    if (bn == 192) launch256p<192>(p, epilogue, s);
+    if (bn == 384) launch256p<384>(p, epilogue, s);
+    else if (bn == 192) launch256p<192>(p, epilogue, s);
     else if (bn == 128) launch256p<128>(p, epilogue, s);
     else launch256p<256>(p, epilogue, s);
 }
