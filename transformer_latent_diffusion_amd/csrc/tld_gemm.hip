@@ -346,25 +346,37 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     // each thread walks TWO image rows (irow, irow + 8) in lockstep: two independent window/FMA/GELU
                     // chains per thread -- with 2 waves per SIMD the single-row form was latency-bound
                     const int irow0 = threadIdx.x >> 6;                  // image rows irow0 and irow0 + 8
-                    auto col = [&](int jj, f32x2 (&c)[2][3][2]) {
-                        const bool jok = jj >= 0 && jj < 16;
+                    // Image-border handling without branches: rows outside the image are read from a clamped (valid) row
+                    // and meet ZERO weights -- only the upper taps of image row 0 (wave 0) and the lower taps of image
+                    // row 15 (wave 7) are affected, so two masked copies of three taps are all it takes.  (Predicated
+                    // loads broke the window loop into ~20 exec-masked blocks per step.)
+                    f32x2 wU[3][2], wD[3][2];
+                    {
+                        const float mu = irow0 > 0 ? 1.0f : 0.0f, md = irow0 < 7 ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int t3 = 0; t3 < 3; ++t3)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) { wU[t3][h2] = w[t3][h2] * mu; wD[t3][h2] = w[6 + t3][h2] * md; }
+                    }
+                    auto col_zero = [&](f32x2 (&c)[2][3][2]) {           // image columns -1 and 16
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                            for (int du = 0; du < 3; ++du) { c[rr][du][0] = f32x2{0.f, 0.f}; c[rr][du][1] = f32x2{0.f, 0.f}; }
+                    };
+                    auto col = [&](int jj, f32x2 (&c)[2][3][2]) {        // 0 <= jj < 16
 #pragma unroll
                         for (int rr = 0; rr < 2; ++rr) {
                             const int irow = irow0 + rr * 8;
 #pragma unroll
                             for (int du = 0; du < 3; ++du) {
-                                const int ir = irow + du - 1;
-                                const bool ok = jok && ir >= 0 && ir < 16;
-                                if (ok) {
-                                    const int tok = ir * 16 + jj;
-                                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(
-                                        H + tok * 512 + ((((cq >> 1) ^ (tok & 31)) << 4) | ((cq & 1) << 3)));
-                                    c[rr][du][0] = f32x2{(float)v[0], (float)v[1]};
-                                    c[rr][du][1] = f32x2{(float)v[2], (float)v[3]};
-                                } else {
-                                    c[rr][du][0] = f32x2{0.f, 0.f};
-                                    c[rr][du][1] = f32x2{0.f, 0.f};
-                                }
+                                int ir = irow + du - 1;
+                                ir = ir < 0 ? 0 : (ir > 15 ? 15 : ir);
+                                const int tok = ir * 16 + jj;
+                                const bf16x4 v = *reinterpret_cast<const bf16x4*>(
+                                    H + tok * 512 + ((((cq >> 1) ^ (tok & 31)) << 4) | ((cq & 1) << 3)));
+                                c[rr][du][0] = f32x2{(float)v[0], (float)v[1]};
+                                c[rr][du][1] = f32x2{(float)v[2], (float)v[3]};
                             }
                         }
                     };
@@ -380,9 +392,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                                 for (int h2 = 0; h2 < 2; ++h2) {
-                                    a[rr][h2] = __builtin_elementwise_fma(w[du * 3 + 0][h2], L[rr][du][h2], a[rr][h2]);
-                                    a[rr][h2] = __builtin_elementwise_fma(w[du * 3 + 1][h2], Mc[rr][du][h2], a[rr][h2]);
-                                    a[rr][h2] = __builtin_elementwise_fma(w[du * 3 + 2][h2], R[rr][du][h2], a[rr][h2]);
+                                    const bool up = (rr == 0 && du == 0), dn = (rr == 1 && du == 2);      // compile-time
+                                    const f32x2 w0 = up ? wU[0][h2] : (dn ? wD[0][h2] : w[du * 3 + 0][h2]);
+                                    const f32x2 w1 = up ? wU[1][h2] : (dn ? wD[1][h2] : w[du * 3 + 1][h2]);
+                                    const f32x2 w2 = up ? wU[2][h2] : (dn ? wD[2][h2] : w[du * 3 + 2][h2]);
+                                    a[rr][h2] = __builtin_elementwise_fma(w0, L[rr][du][h2], a[rr][h2]);
+                                    a[rr][h2] = __builtin_elementwise_fma(w1, Mc[rr][du][h2], a[rr][h2]);
+                                    a[rr][h2] = __builtin_elementwise_fma(w2, R[rr][du][h2], a[rr][h2]);
                                 }
                         if (!TLD_EPI_BIT(2)) {
 #pragma unroll
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         }
                     };
                     f32x2 c0v[2][3][2], c1v[2][3][2], c2v[2][3][2];
-                    col(-1, c0v);
+                    col_zero(c0v);
                     col(0, c1v);
                     int jj = 0;
                     for (; jj + 3 <= 16; jj += 3) {
@@ -405,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         col(jj + 2, c0v); emit(c1v, c2v, c0v, jj + 1);
                         col(jj + 3, c1v); emit(c2v, c0v, c1v, jj + 2);
                     }
-                    col(jj + 1, c2v); emit(c0v, c1v, c2v, jj);       // jj == 15
+                    col_zero(c2v); emit(c0v, c1v, c2v, jj);          // jj == 15
                 }
                 // the ring restarts for the next tile: its first K-step could not be prefetched (LDS was the image)
                 __builtin_amdgcn_s_barrier();
