@@ -408,8 +408,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         for (int rr = 0; rr < 2; ++rr) {
                             bf16x4 o;
                             o[0] = (bf16)a[rr][0][0]; o[1] = (bf16)a[rr][0][1]; o[2] = (bf16)a[rr][1][0]; o[3] = (bf16)a[rr][1][1];
-                            if (m0 + (irow0 + rr * 8) * 16 + jj < (TLD_EPI_BIT(1) ? -1 : p.M))
-                                TLD_STORE(reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 128 + jj) * p.ldo), o);
+                            // (no row guard: this epilogue requires M % 256 == 0 -- one whole image per tile)
+                            if (!TLD_EPI_BIT(1)) TLD_STORE(reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 128 + jj) * p.ldo), o);
                         }
                     };
                     f32x2 c0v[2][3][2], c1v[2][3][2], c2v[2][3][2];
