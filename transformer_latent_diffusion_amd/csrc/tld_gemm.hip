@@ -78,6 +78,8 @@ struct G256P : G256<BN> {
     static constexpr int STAGES = 2;
     static constexpr int STAGE_BYTES = G256<BN>::A_BYTES + G256<BN>::B_BYTES;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static constexpr int IMG_PITCH = 520;            // fused depthwise epilogue: bytes per token row of the LDS image (512 + 8)
+    static constexpr int IMG_BYTES = 256 * IMG_PITCH;
     static constexpr int SCRATCH = 4608;             // per-wave epilogue scratch (8 x 4608 <= one stage)
 };
 
@@ -308,7 +310,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 // stages -- this epilogue therefore gives up the cross-tile prefetch), then every thread slides a
                 // 3x3 fp32 window along an image row for one channel quad, applies bias + exact GELU and stores 8 B.
                 // The pre-conv hidden tensor never travels to HBM (a 200 MB write + read per layer) and the separate
-                // kernel disappears.  16-B chunks of a token row are XOR-swizzled with (token & 31).
+                // kernel disappears.  Token rows have a 520-byte pitch (512 + 8): the 32 tokens a wave writes at one channel
+                // offset then fall on all 64 banks, and reads are plain base + column * 520 (an XOR swizzle cost ~20 VALU
+                // of address arithmetic per window step).  The image (130 KB) spills a little past the two stages.
                 static_assert(BN == 256, "fused depthwise epilogue is written for 256-column tiles");
                 char* H = smem;
                 if (!TLD_EPI_BIT(8))
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             pk[2] = (bf16)(acc[i][j][rq * 4 + 2] + bv.z);
                             pk[3] = (bf16)(acc[i][j][rq * 4 + 3] + bv.w);
                             const int tok = wm * G::WROWS + i * 32 + l31;
-                            *reinterpret_cast<bf16x4*>(H + tok * 512 + ((((cl >> 3) ^ (tok & 31)) << 4) | ((cl & 7) << 1))) = pk;
+                            *reinterpret_cast<bf16x4*>(H + tok * G::IMG_PITCH + cl * 2) = pk;
                         }
                 __builtin_amdgcn_s_barrier();
                 if (!TLD_EPI_BIT(4)) {
@@ -373,8 +377,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                 int ir = irow + du - 1;
                                 ir = ir < 0 ? 0 : (ir > 15 ? 15 : ir);
                                 const int tok = ir * 16 + jj;
-                                const bf16x4 v = *reinterpret_cast<const bf16x4*>(
-                                    H + tok * 512 + ((((cq >> 1) ^ (tok & 31)) << 4) | ((cq & 1) << 3)));
+                                const bf16x4 v = *reinterpret_cast<const bf16x4*>(H + tok * G::IMG_PITCH + cq * 8);
                                 c[rr][du][0] = f32x2{(float)v[0], (float)v[1]};
                                 c[rr][du][1] = f32x2{(float)v[2], (float)v[3]};
                             }
@@ -557,13 +560,14 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
         pg.xcd_ngroups = 2;
 #define TLD_L256P(E)                                                                                  \
     do {                                                                                              \
+        constexpr int lds = (E) == EPI_UP_DWCONV && G::IMG_BYTES > G::LDS_BYTES ? G::IMG_BYTES : G::LDS_BYTES;   \
         static bool once = false;                                                                     \
         if (!once) {                                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E>),                \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
             once = true;                                                                              \
         }                                                                                             \
-        hipLaunchKernelGGL((gemm256p_kernel<BN, E>), grid, block, G::LDS_BYTES, s, pg, nblocks);      \
+        hipLaunchKernelGGL((gemm256p_kernel<BN, E>), grid, block, lds, s, pg, nblocks);               \
     } while (0)
     if constexpr (BN == 192 || BN == 384) {
         TLD_L256P(EPI_BIAS_RESID);
