@@ -98,6 +98,22 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
     const f32x2 hx = x * 0.5f;
     return __builtin_elementwise_fma(hx, e, hx);
 }
+// GELU of 2y given y (the fused depthwise epilogue halves the conv weights and bias on the host -- exact -- so the conv
+// delivers y = x / 2):  GELU(x) = y (1 + erf(sqrt2 y)), with sqrt2^i folded into the A&S coefficients.  Two packed
+// multiplies per pair fewer than gelu_erf_fast2(x).
+__device__ __forceinline__ f32x2 gelu_erf_fast2_half(f32x2 y) {
+    const f32x2 ay = __builtin_elementwise_abs(y);
+    f32x2 p = __builtin_elementwise_fma(f32x2{0.0003445104f, 0.0003445104f}, ay, f32x2{0.001564500341f, 0.001564500341f});
+    p = __builtin_elementwise_fma(p, ay, f32x2{0.0006080572f, 0.0006080572f});
+    p = __builtin_elementwise_fma(p, ay, f32x2{0.02622101059f, 0.02622101059f});
+    p = __builtin_elementwise_fma(p, ay, f32x2{0.0845640246f, 0.0845640246f});
+    p = __builtin_elementwise_fma(p, ay, f32x2{0.09973469393f, 0.09973469393f});
+    p = __builtin_elementwise_fma(p, ay, f32x2{1.0f, 1.0f});
+    f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+    r *= r; r *= r; r *= r; r *= r;
+    const f32x2 e = {copysignf(1.0f - r[0], y[0]), copysignf(1.0f - r[1], y[1])};       // erf(x / sqrt2)
+    return __builtin_elementwise_fma(y, e, y);
+}
 // (A transcendental-free degree-9 polynomial erf was measured ~4 % SLOWER end to end: its 10-deep dependent FMA
 // chain is latency-bound at the 2 waves/SIMD of the fused GEMM epilogue.)
 
@@ -174,8 +190,8 @@ struct GemmParams {
     bf16* vt;                     // EPI_QKV
     int ntok, d;                  // EPI_QKV
     const float* bias;            // EPI_BIAS_*
-    const float* dw_w9c;          // EPI_UP_DWCONV: depthwise weights [9][N]
-    const float* dw_b;            // EPI_UP_DWCONV: depthwise bias [N]
+    const float* dw_w9c;          // EPI_UP_DWCONV: HALVED depthwise weights [9][N]  (the epilogue's GELU takes x / 2)
+    const float* dw_b;            // EPI_UP_DWCONV: HALVED depthwise bias [N]
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
     unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0

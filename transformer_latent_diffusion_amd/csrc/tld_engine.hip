@@ -53,6 +53,7 @@ struct HostTensor {
 struct Layer {
     bf16 *qkv_w = nullptr, *up_w = nullptr, *down_w = nullptr;
     float *up_b = nullptr, *dw_w9c = nullptr, *dw_b = nullptr, *down_b = nullptr;
+    float *dw_w9c_half = nullptr, *dw_b_half = nullptr;   // 0.5 x (exact): operands of the fused up-projection epilogue
     float *n1_w = nullptr, *n1_b = nullptr, *n2_w = nullptr, *n2_b = nullptr, *n3_w = nullptr, *n3_b = nullptr;
     float *kv_w = nullptr, *q_w = nullptr;   // fp32, conditioning path
 };
@@ -288,7 +289,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             ProfScope ps(e, KC_GEMM_UP, s);
             GemmParams g{};
             g.A = e->xn; g.lda = d; g.W = Ly.up_w; g.ldw = d; g.M = M; g.N = e->hid; g.K = d;
-            g.out_bf16 = e->hid2; g.ldo = e->hid; g.bias = Ly.up_b; g.dw_w9c = Ly.dw_w9c; g.dw_b = Ly.dw_b;
+            g.out_bf16 = e->hid2; g.ldo = e->hid; g.bias = Ly.up_b; g.dw_w9c = Ly.dw_w9c_half; g.dw_b = Ly.dw_b_half;
             launch_gemm(g, EPI_UP_DWCONV, s);
         } else {
             {   // hid1 = xn Wup^T + b
@@ -453,6 +454,15 @@ int tld_engine_finalize_weights(tld_engine* e) {
             if (int rc = dev_alloc(e, &Ly.dw_w9c, (size_t)(hid * 9))) return rc;
             HIP_TRY(hipMemcpy(Ly.dw_w9c, tr.data(), tr.size() * sizeof(float), hipMemcpyHostToDevice));
             e->weight_bytes += (int64_t)tr.size() * 4;
+            // halved copies for the fused epilogue (its GELU is written for x / 2; scaling by 0.5 is exact)
+            std::vector<float> hb(e->host[LK("mlp.mlp.1.bias")].data);
+            for (float& v : tr) v *= 0.5f;
+            for (float& v : hb) v *= 0.5f;
+            if (int rc = dev_alloc(e, &Ly.dw_w9c_half, tr.size())) return rc;
+            if (int rc = dev_alloc(e, &Ly.dw_b_half, hb.size())) return rc;
+            HIP_TRY(hipMemcpy(Ly.dw_w9c_half, tr.data(), tr.size() * sizeof(float), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(Ly.dw_b_half, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+            e->weight_bytes += (int64_t)(tr.size() + hb.size()) * 4;
         }
 #undef LK
     }

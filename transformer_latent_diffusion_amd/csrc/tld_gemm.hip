@@ -405,7 +405,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                 }
                         if (!TLD_EPI_BIT(2)) {
 #pragma unroll
-                            for (int rr = 0; rr < 2; ++rr) { a[rr][0] = gelu_erf_fast2(a[rr][0]); a[rr][1] = gelu_erf_fast2(a[rr][1]); }
+                            for (int rr = 0; rr < 2; ++rr) { a[rr][0] = gelu_erf_fast2_half(a[rr][0]); a[rr][1] = gelu_erf_fast2_half(a[rr][1]); }
                         }
 #pragma unroll
                         for (int rr = 0; rr < 2; ++rr) {
