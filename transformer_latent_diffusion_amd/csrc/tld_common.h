@@ -150,6 +150,9 @@ __device__ __forceinline__ void rs_store4(resid_t* p, float4 v) {
 #endif
 }
 
+// value the residual stream will hold after a store (what a later LayerNorm of the stored row sees)
+__device__ __forceinline__ float rs_round(float v) { return (float)(resid_t)v; }
+
 #ifndef TLD_DW_GELU
 #define TLD_DW_GELU gelu_erf_fast
 #endif
@@ -193,6 +196,10 @@ struct GemmParams {
     const float* dw_w9c;          // EPI_UP_DWCONV: HALVED depthwise weights [9][N]  (the epilogue's GELU takes x / 2)
     const float* dw_b;            // EPI_UP_DWCONV: HALVED depthwise bias [N]
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
+    // EPI_UP_DWCONV with LayerNorm-3 folded in: A is the raw bf16 residual stream, W = bf16(gamma3 (.) Wup),
+    // bias = up_b + beta3 . Wup^T, and the image write applies  rstd_m (acc - mean_m c1[n]) + bias[n]
+    const float2* row_stats;      // [M] (mean, rstd) per row; null: A is already normalized
+    const float* ln_c1;           // [N] column sums of the gamma-scaled bf16 weights
     unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0
     int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop
@@ -244,11 +251,14 @@ struct CrossRowParams {
     const int* label_row;         // [B] token row of each sample's label token
     const float* ln2_w; const float* ln2_b;
     const float* ln3_w; const float* ln3_b;
-    bf16* xn3;                    // [M,d]
+    bf16* xn3;                    // [M,d]  LN3(x) for the up-projection (null when ln3_stats is used instead)
+    float2* ln3_stats;            // optional [M]: (mean, rstd) of the ROUNDED new residual row -- LN3 is then applied
+                                  // inside the fused up-projection's epilogue and xn3 is never written
     float* sa_out;                // optional debug dump of x + att  [M,d]
     int batch, ntok, d, heads;
 };
 void launch_cross_row(const CrossRowParams& p, hipStream_t s);
+bool cross_row_supports_ln3_stats(int d);
 
 struct TailParams {
     const resid_t* tok;           // [B*N, d]

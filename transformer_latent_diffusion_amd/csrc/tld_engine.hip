@@ -54,6 +54,8 @@ struct Layer {
     bf16 *qkv_w = nullptr, *up_w = nullptr, *down_w = nullptr;
     float *up_b = nullptr, *dw_w9c = nullptr, *dw_b = nullptr, *down_b = nullptr;
     float *dw_w9c_half = nullptr, *dw_b_half = nullptr;   // 0.5 x (exact): operands of the fused up-projection epilogue
+    bf16 *up_wf = nullptr;                                // bf16(gamma3 (.) Wup): LayerNorm-3 folded into the up-projection
+    float *up_c1 = nullptr, *up_b1 = nullptr;             // [hid] column sums of up_wf; up_b + beta3 . Wup^T
     float *n1_w = nullptr, *n1_b = nullptr, *n2_w = nullptr, *n2_b = nullptr, *n3_w = nullptr, *n3_b = nullptr;
     float *kv_w = nullptr, *q_w = nullptr;   // fp32, conditioning path
 };
@@ -85,6 +87,8 @@ struct tld_engine {
     resid_t* x = nullptr;
     resid_t* x_half = nullptr;         // patch embedding of the un-doubled batch (CFG layer-0 sharing)
     bool share_l0 = true;              // TLD_SHARE_L0=0 disables (A/B testing)
+    bool fold_ln3 = true;              // TLD_FOLD_LN3=0: cross_row writes LN3(x) and the up-projection reads it (A/B testing)
+    float2* row_stats = nullptr;       // [M] (mean, rstd) of the residual rows, cross_row -> up-projection epilogue
     bf16 *xn = nullptr, *qk = nullptr, *vt = nullptr, *att = nullptr, *hid1 = nullptr, *hid2 = nullptr;
     float *io_x = nullptr, *io_sigma = nullptr, *io_label = nullptr, *io_out = nullptr;
     float *xt = nullptr, *x0_prev = nullptr, *x0_cfg = nullptr;
@@ -266,6 +270,10 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             if (int rc = dev_alloc(e, &buf, (size_t)e->cfg.max_batch * e->ntok * d)) return rc;
             e->stages["blk0_sa"] = buf;
         }
+        // 256 px (16x16 tokens): one GEMM tile row-block is one image, so the depthwise conv + GELU run inside the
+        // up-projection's epilogue and the pre-conv hidden never reaches HBM.  Other grids: separate kernels.
+        const bool fuse_dw = e->fuse_dwconv && e->grid == 16 && e->hid % 256 == 0;
+        const bool fold3 = fuse_dw && e->fold_ln3;      // LN3 applied in that epilogue: cross_row writes row statistics, not xn
         {   // x += att; x += CA(LN2 x, y); xn = LN3(x)
             ProfScope ps(e, KC_CROSS, s);
             CrossRowParams cp{};
@@ -277,19 +285,21 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             cp.v_ld = 2 * d;
             cp.noise_row = noise_row; cp.label_row = label_row;
             cp.ln2_w = Ly.n2_w; cp.ln2_b = Ly.n2_b; cp.ln3_w = Ly.n3_w; cp.ln3_b = Ly.n3_b;
-            cp.xn3 = e->xn; cp.batch = batch; cp.ntok = e->ntok; cp.d = d; cp.heads = e->H;
+            cp.xn3 = fold3 ? nullptr : e->xn; cp.ln3_stats = fold3 ? e->row_stats : nullptr; cp.batch = batch; cp.ntok = e->ntok; cp.d = d; cp.heads = e->H;
             cp.sa_out = (l == 0 && e->debug) ? e->stages["blk0_sa"] : nullptr;
             launch_cross_row(cp, s);
         }
         if (l == 0) if (int rc = capture(e, "blk0_ca", e->x, (size_t)M * d, s)) return rc;
-        // 256 px (16x16 tokens): one GEMM tile row-block is one image, so the depthwise conv + GELU run inside the
-        // up-projection's epilogue and the pre-conv hidden never reaches HBM.  Other grids: separate kernels.
-        const bool fuse_dw = e->fuse_dwconv && e->grid == 16 && e->hid % 256 == 0;
         if (fuse_dw) {
             ProfScope ps(e, KC_GEMM_UP, s);
             GemmParams g{};
             g.A = e->xn; g.lda = d; g.W = Ly.up_w; g.ldw = d; g.M = M; g.N = e->hid; g.K = d;
             g.out_bf16 = e->hid2; g.ldo = e->hid; g.bias = Ly.up_b; g.dw_w9c = Ly.dw_w9c_half; g.dw_b = Ly.dw_b_half;
+#ifdef TLD_RESID_BF16
+            if (fold3) {    // LN3 inside the epilogue: raw residual rows x gamma-scaled weights, statistics from cross_row
+                g.A = e->x; g.W = Ly.up_wf; g.bias = Ly.up_b1; g.ln_c1 = Ly.up_c1; g.row_stats = e->row_stats;
+            }
+#endif
             launch_gemm(g, EPI_UP_DWCONV, s);
         } else {
             {   // hid1 = xn Wup^T + b
@@ -373,6 +383,12 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     e->layers.resize(e->L);
     if (const char* fd = getenv("TLD_FUSE_DWCONV")) e->fuse_dwconv = atoi(fd) != 0;
     if (const char* sl = getenv("TLD_SHARE_L0")) e->share_l0 = atoi(sl) != 0;
+    if (const char* fl = getenv("TLD_FOLD_LN3")) e->fold_ln3 = atoi(fl) != 0;
+#ifndef TLD_RESID_BF16
+    e->fold_ln3 = false;               // the fold feeds the bf16 residual stream straight to the MFMA
+#endif
+    // only where the fused up-projection and the statistics-writing row kernel exist
+    e->fold_ln3 = e->fold_ln3 && e->fuse_dwconv && grid == 16 && e->hid % 256 == 0 && cross_row_supports_ln3_stats(e->d);
     *out = e;
     return TLD_OK;
 }
@@ -444,6 +460,32 @@ int tld_engine_finalize_weights(tld_engine* e) {
         if (int rc = upload_f32(e, LK("norm2.bias"), &Ly.n2_b, d)) return rc;
         if (int rc = upload_f32(e, LK("norm3.weight"), &Ly.n3_w, d)) return rc;
         if (int rc = upload_f32(e, LK("norm3.bias"), &Ly.n3_b, d)) return rc;
+        if (e->fold_ln3) {
+            const std::vector<float>& W = e->host[LK("mlp.mlp.0.weight")].data;      // [hid][d]  (1x1 conv = Linear)
+            const std::vector<float>& ub = e->host[LK("mlp.mlp.0.bias")].data;
+            const std::vector<float>& g3 = e->host[LK("norm3.weight")].data;
+            const std::vector<float>& b3 = e->host[LK("norm3.bias")].data;
+            std::vector<uint16_t> wf((size_t)(hid * d));
+            std::vector<float> c1((size_t)hid), b1((size_t)hid);
+            for (int64_t n = 0; n < hid; ++n) {
+                double sc = 0.0, sb = 0.0;
+                for (int64_t k2 = 0; k2 < d; ++k2) {
+                    const float w = W[(size_t)(n * d + k2)];
+                    const uint16_t q = f32_to_bf16_rne(g3[(size_t)k2] * w);
+                    wf[(size_t)(n * d + k2)] = q;
+                    uint32_t u = (uint32_t)q << 16; float qf; memcpy(&qf, &u, 4);
+                    sc += qf; sb += (double)b3[(size_t)k2] * w;
+                }
+                c1[(size_t)n] = (float)sc; b1[(size_t)n] = (float)(sb + ub[(size_t)n]);
+            }
+            if (int rc = dev_alloc(e, &Ly.up_wf, wf.size())) return rc;
+            if (int rc = dev_alloc(e, &Ly.up_c1, c1.size())) return rc;
+            if (int rc = dev_alloc(e, &Ly.up_b1, b1.size())) return rc;
+            HIP_TRY(hipMemcpy(Ly.up_wf, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(Ly.up_c1, c1.data(), c1.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(Ly.up_b1, b1.data(), b1.size() * 4, hipMemcpyHostToDevice));
+            e->weight_bytes += (int64_t)wf.size() * 2 + (int64_t)c1.size() * 8;
+        }
         {   // depthwise weight [hid,1,3,3] -> [9][hid]
             auto it = e->host.find(LK("mlp.mlp.1.weight"));
             if (it == e->host.end()) return fail(TLD_ERR_STATE, "state_dict entry missing: %s", key);
@@ -484,6 +526,7 @@ int tld_engine_finalize_weights(tld_engine* e) {
     if (int rc = dev_alloc(e, &e->x, M * d)) return rc;
     if (int rc = dev_alloc(e, &e->x_half, (M + 1) / 2 * d)) return rc;
     if (int rc = dev_alloc(e, &e->xn, M * d)) return rc;
+    if (int rc = dev_alloc(e, &e->row_stats, M + 256)) return rc;
     if (int rc = dev_alloc(e, &e->qk, M * 2 * d)) return rc;
     if (int rc = dev_alloc(e, &e->vt, M * d)) return rc;
     if (int rc = dev_alloc(e, &e->att, M * d)) return rc;

@@ -80,6 +80,8 @@ struct G256P : G256<BN> {
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
     static constexpr int IMG_PITCH = 520;            // fused depthwise epilogue: bytes per token row of the LDS image (512 + 8)
     static constexpr int IMG_BYTES = 256 * IMG_PITCH;
+    static constexpr int ROWSTAT_OFF = IMG_BYTES;    // folded LayerNorm-3: the tile's 256 (mean, rstd) pairs, behind the image
+    static constexpr int UPDW_LDS = IMG_BYTES + 256 * 8;
     static constexpr int SCRATCH = 4608;             // per-wave epilogue scratch (8 x 4608 <= one stage)
 };
 
@@ -235,6 +237,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 stamp(k, 1);
                 __builtin_amdgcn_s_barrier();      // everybody's; stage (g+1)&1 (operands or epilogue scratch) is idle
                 stamp(k, 2);
+                if constexpr (EPI == EPI_UP_DWCONV) {
+                    // folded LayerNorm-3: the tile's 256 (mean, rstd) pairs travel by DMA into LDS behind the image while
+                    // the K loop runs (K-step 1: every wave is past the previous tile's epilogue, which read them)
+                    if (k == 1 && p.row_stats && wid < 2) {
+                        const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::ROWSTAT_OFF + wid * 1024), 16, 0, 0);
+                    }
+                }
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
                 const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV);
@@ -315,23 +325,40 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 // of address arithmetic per window step).  The image (130 KB) spills a little past the two stages.
                 static_assert(BN == 256, "fused depthwise epilogue is written for 256-column tiles");
                 char* H = smem;
+                // LayerNorm-3 folded in (p.row_stats): acc is x W'^T for the RAW residual rows; the image gets
+                // rstd_m (acc - mean_m c1[n]) + b1[n] = rs * acc + (nm * c1 + b1), lane = token row m
+                float ln_rs[G::TM], ln_nm[G::TM];
+                const bool ln3 = p.row_stats != nullptr;
+#pragma unroll
+                for (int i = 0; i < G::TM; ++i) {
+                    ln_rs[i] = 1.0f; ln_nm[i] = 0.f;
+                    if (ln3) {
+                        const float2 st = *reinterpret_cast<const float2*>(smem + G::ROWSTAT_OFF + (wm * G::WROWS + i * 32 + l31) * 8);
+                        ln_rs[i] = st.y; ln_nm[i] = -st.y * st.x;
+                    }
+                }
+                // (column-major over the wave tile: the per-column constants are fetched once per 4 columns, not once per
+                // 32-row MFMA tile -- 16 instead of 64 global loads per lane and tile)
                 if (!TLD_EPI_BIT(8))
 #pragma unroll
-                for (int i = 0; i < G::TM; ++i)
+                for (int j = 0; j < G::TN; ++j)
 #pragma unroll
-                    for (int j = 0; j < G::TN; ++j)
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int cl = wn * 64 + j * 32 + 8 * rq + 4 * hi;               // channel inside the tile
+                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + cl);
+                        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ln3) c4 = *reinterpret_cast<const float4*>(p.ln_c1 + n0 + cl);
 #pragma unroll
-                        for (int rq = 0; rq < 4; ++rq) {
-                            const int cl = wn * 64 + j * 32 + 8 * rq + 4 * hi;               // channel inside the tile
-                            const float4 bv = *reinterpret_cast<const float4*>(p.bias + n0 + cl);
+                        for (int i = 0; i < G::TM; ++i) {
                             bf16x4 pk;
-                            pk[0] = (bf16)(acc[i][j][rq * 4 + 0] + bv.x);
-                            pk[1] = (bf16)(acc[i][j][rq * 4 + 1] + bv.y);
-                            pk[2] = (bf16)(acc[i][j][rq * 4 + 2] + bv.z);
-                            pk[3] = (bf16)(acc[i][j][rq * 4 + 3] + bv.w);
+                            pk[0] = (bf16)fmaf(ln_rs[i], acc[i][j][rq * 4 + 0], fmaf(ln_nm[i], c4.x, b4.x));
+                            pk[1] = (bf16)fmaf(ln_rs[i], acc[i][j][rq * 4 + 1], fmaf(ln_nm[i], c4.y, b4.y));
+                            pk[2] = (bf16)fmaf(ln_rs[i], acc[i][j][rq * 4 + 2], fmaf(ln_nm[i], c4.z, b4.z));
+                            pk[3] = (bf16)fmaf(ln_rs[i], acc[i][j][rq * 4 + 3], fmaf(ln_nm[i], c4.w, b4.w));
                             const int tok = wm * G::WROWS + i * 32 + l31;
                             *reinterpret_cast<bf16x4*>(H + tok * G::IMG_PITCH + cl * 2) = pk;
                         }
+                    }
                 __builtin_amdgcn_s_barrier();
                 if (!TLD_EPI_BIT(4)) {
                     const int cq = threadIdx.x & 63;                     // channel quad (64 per token row)
@@ -560,7 +587,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
         pg.xcd_ngroups = 2;
 #define TLD_L256P(E)                                                                                  \
     do {                                                                                              \
-        constexpr int lds = (E) == EPI_UP_DWCONV && G::IMG_BYTES > G::LDS_BYTES ? G::IMG_BYTES : G::LDS_BYTES;   \
+        constexpr int lds = (E) == EPI_UP_DWCONV && G::UPDW_LDS > G::LDS_BYTES ? G::UPDW_LDS : G::LDS_BYTES;     \
         static bool once = false;                                                                     \
         if (!once) {                                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E>),                \

@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, 
     }
     if (threadIdx.x < H) bw[threadIdx.x] = p.bwq[(size_t)tl * H + threadIdx.x] - p.bwq[(size_t)tn * H + threadIdx.x];
     __syncthreads();
+    const bool fold3 = p.ln3_stats != nullptr;
     float bwl[NQ];
 #pragma unroll
     for (int hg = 0; hg < NQ; ++hg) bwl[hg] = bw[4 * hg + (lane >> 4)];
@@ -535,6 +536,10 @@ __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, 
                 const f32x4 pl = {plab[u][j], plab[u][j], plab[u][j], plab[u][j]};
                 v[u][j] += __builtin_elementwise_fma(pl, dd, a);
                 rs_store4(p.x + (row + u) * d + n, make_float4(v[u][j][0], v[u][j][1], v[u][j][2], v[u][j][3]));
+                if (fold3) {        // LN3 is applied by the consumer GEMM to the STORED (rounded) row: take its statistics
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) v[u][j][e2] = rs_round(v[u][j][e2]);
+                }
                 s4 += v[u][j];
             }
             mean3[u] = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_d;
@@ -548,6 +553,13 @@ __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, 
                 q4 = __builtin_elementwise_fma(v[u][j], v[u][j], q4);
             }
             rstd3[u] = __builtin_amdgcn_rsqf(fmaf(wave_sum((q4[0] + q4[1]) + (q4[2] + q4[3])), inv_d, kLnEps));
+        }
+        if (fold3) {
+            if (lane == 0) {
+                p.ln3_stats[row] = make_float2(mean3[0], rstd3[0]);
+                p.ln3_stats[row + 1] = make_float2(mean3[1], rstd3[1]);
+            }
+            continue;
         }
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
@@ -840,6 +852,12 @@ void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf1
     if (q4 && d == 256) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
     if (q4 && d == 1024) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
     TLD_DISPATCH_NJ(d / 128, hipLaunchKernelGGL(layernorm_bf16_kernel<NJ>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d));
+}
+
+// the LN3-statistics output (CrossRowParams::ln3_stats) exists in the 4-features-per-lane kernel only
+bool cross_row_supports_ln3_stats(int d) {
+    static const bool q4 = !(getenv("TLD_CROSS_Q4") && atoi(getenv("TLD_CROSS_Q4")) == 0);
+    return q4 && (d == 768 || d == 512 || d == 256);
 }
 
 void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
