@@ -241,3 +241,32 @@ def test_bf16_io_matches_fp32_io():
     o32r = m(xb.float(), s.bfloat16().float(), lb.float())
     assert rel_rms(ob.float().cpu().numpy(), o32r.cpu().numpy()) <= 1e-2
     assert torch.isfinite(o32).all()
+
+
+_FALLBACK_SNIPPET = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from test_gpu_parity import load_golden, _engine, _t, rel_rms
+g = load_golden("g5_100m.npz")
+cfg, sd, m = _engine(g)
+out = m(_t(g["x"]), _t(g["sigma"]), _t(g["label"])).cpu().numpy()
+print("REL", rel_rms(out, g["x0"]))
+"""
+
+
+@pytest.mark.parametrize("knobs", [{"TLD_FOLD_LN3": "0"}, {"TLD_FUSE_DWCONV": "0"}, {"TLD_DOWN_BN384": "0"},
+                                   {"TLD_CROSS_Q4": "0", "TLD_LN_Q4": "0"}, {"TLD_SHARE_L0": "0", "TLD_ATTN_8W": "1"}])
+def test_fallback_paths_vs_golden(knobs):
+    """The A/B switches select older code paths that stay in the tree (and serve other shapes): each must still
+    reproduce the 100 M golden forward.  The switches are read once per process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    tests = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(tests)
+    env = dict(os.environ, **knobs)
+    r = subprocess.run([sys.executable, "-c", _FALLBACK_SNIPPET.format(root=root, tests=tests)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rel = float([ln for ln in r.stdout.splitlines() if ln.startswith("REL")][-1].split()[1])
+    assert rel <= FWD_TOL, (knobs, rel)
