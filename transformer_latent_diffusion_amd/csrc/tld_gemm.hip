@@ -198,8 +198,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         int m0n = 0, n0n = 0;
         const bool has_next = it + 1 < my_tiles;
         if (has_next) tile_coords(it + 1, m0n, n0n);
-        bool swapped = (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID || EPI == EPI_UP_DWCONV);
-        if constexpr (EPI == EPI_QKV) swapped = n0 < 2 * p.d;
+        // MFMA operand order: swapped (D^T = W A^T: a lane owns a token row and 4 consecutive columns per register quad)
+        // everywhere except the fp32 debug epilogue.  The V^T tiles of the QKV GEMM are swapped too and transposed on
+        // their way through the epilogue scratch with 2-byte LDS writes: one K-loop instantiation instead of two took
+        // the kernel from 245 to 213 VGPRs and 111 -> 110 us.
+        constexpr bool swapped = EPI != EPI_F32;
+        bool v_tile = false;
+        if constexpr (EPI == EPI_QKV) v_tile = n0 >= 2 * p.d;
 
         f32x16 acc[G::TM][G::TN];
 #pragma unroll
@@ -288,13 +293,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             }
             if constexpr (BN != 384) mma(a1, b1);  // k-slice 3 of the tile's last step
         };
-        if constexpr (EPI == EPI_QKV) {
-            if (swapped) kloop(std::true_type{}); else kloop(std::false_type{});
-        } else if constexpr (EPI == EPI_F32) {
-            kloop(std::false_type{});
-        } else {
-            kloop(std::true_type{});
-        }
+        if constexpr (swapped) kloop(std::true_type{}); else kloop(std::false_type{});
 
         const int row0 = m0 + wm * G::WROWS;
         const int col0 = n0 + wn * G::WCOLS;
@@ -491,7 +490,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 // hoisted out of the tile loop and lives (or spills) across the K loops
                 int e_lane = lane, e_l31 = l31, e_hi = hi;
                 asm volatile("" : "+v"(e_lane), "+v"(e_l31), "+v"(e_hi));
-                const bool to_vt = (EPI == EPI_QKV) && !swapped;
+                const bool to_vt = (EPI == EPI_QKV) && v_tile;
                 if (!to_vt) {
                     // one 32-row x 64-col bf16 slab per pass: 128-B pitch, 16-B chunks XOR-swizzled with (row & 7)
                     constexpr int P = 128;
@@ -540,10 +539,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 #pragma unroll
                                 for (int rq = 0; rq < 4; ++rq) {
                                     const int i = half * 2 + ii;
-                                    bf16x4 pk;
-                                    pk[0] = (bf16)acc[i][j][rq * 4 + 0]; pk[1] = (bf16)acc[i][j][rq * 4 + 1];
-                                    pk[2] = (bf16)acc[i][j][rq * 4 + 2]; pk[3] = (bf16)acc[i][j][rq * 4 + 3];
-                                    *reinterpret_cast<bf16x4*>(ws + e_l31 * P + (ii * 32 + 8 * rq + 4 * e_hi) * 2) = pk;
+                                    // swapped accumulators: lane = token, registers = features -> 2-byte writes
+#pragma unroll
+                                    for (int e2 = 0; e2 < 4; ++e2)
+                                        *reinterpret_cast<bf16*>(ws + (8 * rq + 4 * e_hi + e2) * P + (ii * 32 + e_l31) * 2) = (bf16)acc[i][j][rq * 4 + e2];
                                 }
 #pragma unroll
                             for (int itr = 0; itr < 4; ++itr) {
