@@ -180,6 +180,7 @@ enum GemmEpilogue {
     EPI_QKV = 1,         // q,k -> bf16 [M,2d] ; v -> bf16 transposed per (sample, head): [B,H,64,Ntok]
     EPI_BIAS_BF16 = 2,   // bf16(C + bias[n]) -> [M,N]           (MLP up projection)
     EPI_BIAS_RESID = 3,  // x[m,n] += C + bias[n] (resid_t)      (MLP down projection)
+    EPI_QKV_LN = 5,      // EPI_QKV with LayerNorm-1 folded in (A = raw residual stream, see GemmParams::ln_stats)
     EPI_UP_DWCONV = 4,   // bf16(C + bias) -> depthwise 3x3 + bias + GELU over the tile's 16x16 image -> [M,N]
                          // (MLP up projection fused with the depthwise conv; needs ntok == 256, BN == 256)
 };
@@ -196,6 +197,15 @@ struct GemmParams {
     const float* dw_w9c;          // EPI_UP_DWCONV: HALVED depthwise weights [9][N]  (the epilogue's GELU takes x / 2)
     const float* dw_b;            // EPI_UP_DWCONV: HALVED depthwise bias [N]
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
+    // LayerNorm-1 folded into the QKV GEMM (EPI_QKV_LN): the producers of the residual stream (embed, EPI_BIAS_RESID)
+    // leave per-row partial sums (sum x, sum x^2) of the ROUNDED values, one slot per 96-column group (slot index =
+    // column / 96, the same for 192- and 384-wide tiles, so results do not depend on the tile shape chosen for a
+    // batch size); the QKV GEMM multiplies the raw residual by bf16(gamma1 (.) Wqkv) and its epilogue applies
+    // rstd_m (acc - mean_m c1[n]) + b1[n].
+    float2* stats_out;            // EPI_BIAS_RESID: [M][kLnSlots] partials out (null: none)
+    const float2* ln_stats;       // EPI_QKV_LN: [M][kLnSlots] partials of the A rows
+    int ln_slots;                 // EPI_QKV_LN: slots to sum per row (even, <= kLnSlots)
+    const float* ln_b1;           // EPI_QKV_LN: [N] beta1 . Wqkv^T   (ln_c1 below holds the column sums)
     // EPI_UP_DWCONV with LayerNorm-3 folded in: A is the raw bf16 residual stream, W = bf16(gamma3 (.) Wup),
     // bias = up_b + beta3 . Wup^T, and the image write applies  rstd_m (acc - mean_m c1[n]) + bias[n]
     const float2* row_stats;      // [M] (mean, rstd) per row; null: A is already normalized
@@ -207,6 +217,9 @@ struct GemmParams {
 };
 
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s);
+constexpr int kLnSlots = 8;
+// slots an EPI_BIAS_RESID launch of width N writes for every batch size (0: shape not supported -> keep the LN kernel)
+int gemm_resid_stat_slots(int N);
 
 
 // self-attention over ntok tokens, head_dim 64: softmax(q k^T / 8) v -> att bf16 [M, d]
@@ -227,6 +240,7 @@ struct EmbedParams {
     const float* ln2_w; const float* ln2_b;   // [d]
     const float* pos;             // [N, d]
     resid_t* tok;                 // [B*N, d]
+    float2* stats_out;            // optional [B*N][kLnSlots]: slot 0 <- (sum, sum of squares) of the rounded row, slot 1 <- 0
     int batch, src_batch;         // model sample b reads latent b % src_batch (CFG doubling without a copy)
     int C, S, p, grid, pd, d, ntok;
 };

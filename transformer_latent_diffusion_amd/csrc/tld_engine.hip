@@ -52,6 +52,8 @@ struct HostTensor {
 
 struct Layer {
     bf16 *qkv_w = nullptr, *up_w = nullptr, *down_w = nullptr;
+    bf16 *qkv_wf = nullptr;                               // bf16(gamma1 (.) Wqkv): LayerNorm-1 folded into the QKV GEMM
+    float *qkv_c1 = nullptr, *qkv_b1 = nullptr;           // [3d] column sums of qkv_wf; beta1 . Wqkv^T
     float *up_b = nullptr, *dw_w9c = nullptr, *dw_b = nullptr, *down_b = nullptr;
     float *dw_w9c_half = nullptr, *dw_b_half = nullptr;   // 0.5 x (exact): operands of the fused up-projection epilogue
     bf16 *up_wf = nullptr;                                // bf16(gamma3 (.) Wup): LayerNorm-3 folded into the up-projection
@@ -87,6 +89,8 @@ struct tld_engine {
     resid_t* x = nullptr;
     resid_t* x_half = nullptr;         // patch embedding of the un-doubled batch (CFG layer-0 sharing)
     bool share_l0 = true;              // TLD_SHARE_L0=0 disables (A/B testing)
+    bool fold_ln1 = true;              // TLD_FOLD_LN1=0: separate LayerNorm-1 kernel (A/B testing)
+    float2* ln_stats = nullptr;        // [M][kLnSlots] row partial sums of the residual stream (embed / down GEMM -> QKV GEMM)
     bool fold_ln3 = true;              // TLD_FOLD_LN3=0: cross_row writes LN3(x) and the up-projection reads it (A/B testing)
     float2* row_stats = nullptr;       // [M] (mean, rstd) of the residual rows, cross_row -> up-projection epilogue
     bf16 *xn = nullptr, *qk = nullptr, *vt = nullptr, *att = nullptr, *hid1 = nullptr, *hid2 = nullptr;
@@ -235,12 +239,14 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
     share_l0 = share_l0 && e->share_l0 && batch == 2 * src_batch && !e->debug;
     const int b0 = share_l0 ? src_batch : batch;            // samples processed up to block 0's attention
     resid_t* xe = share_l0 ? e->x_half : e->x;
+    const bool fold1 = e->fold_ln1;                          // LayerNorm-1 applied inside the QKV GEMM's epilogue
+    const int ln_slots = gemm_resid_stat_slots(d);
     {
         ProfScope ps(e, KC_EMBED, s);
         EmbedParams ep{};
         ep.x = x_src; ep.conv_w = e->conv_w; ep.conv_b = e->conv_b; ep.ln1_w = e->pln1_w; ep.ln1_b = e->pln1_b;
         ep.lin_wt = e->plin_wt; ep.lin_b = e->plin_b; ep.ln2_w = e->pln2_w; ep.ln2_b = e->pln2_b; ep.pos = e->pos;
-        ep.tok = xe; ep.batch = b0; ep.src_batch = src_batch; ep.C = e->cfg.n_channels;
+        ep.tok = xe; ep.stats_out = fold1 ? e->ln_stats : nullptr; ep.batch = b0; ep.src_batch = src_batch; ep.C = e->cfg.n_channels;
         ep.S = e->cfg.image_size; ep.p = e->cfg.patch_size; ep.grid = e->grid; ep.pd = e->pd; ep.d = d;
         ep.ntok = e->ntok;
         launch_embed(ep, s);
@@ -250,16 +256,22 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
         const Layer& Ly = e->layers[l];
         const bool half = share_l0 && l == 0;
         const int bl = half ? b0 : batch, Ml = bl * e->ntok;
-        {   // xn = LN1(x)
+        if (!fold1) {   // xn = LN1(x)
             ProfScope ps(e, KC_LN, s);
             launch_layernorm_bf16(half ? xe : e->x, Ly.n1_w, Ly.n1_b, e->xn, Ml, d, s);
         }
-        {   // q|k, v^T = xn Wqkv^T
+        {   // q|k, v^T = LN1(x) Wqkv^T
             ProfScope ps(e, KC_GEMM_QKV, s);
             GemmParams g{};
             g.A = e->xn; g.lda = d; g.W = Ly.qkv_w; g.ldw = d; g.M = Ml; g.N = 3 * d; g.K = d;
             g.out_bf16 = e->qk; g.ldo = 2 * d; g.vt = e->vt; g.ntok = e->ntok; g.d = d;
-            launch_gemm(g, EPI_QKV, s);
+#ifdef TLD_RESID_BF16
+            if (fold1) {    // raw residual rows x gamma-scaled weights; partial sums from embed (block 0) / the down projection
+                g.A = half ? xe : e->x; g.W = Ly.qkv_wf; g.ln_stats = e->ln_stats; g.ln_slots = l == 0 ? 2 : ln_slots;
+                g.ln_c1 = Ly.qkv_c1; g.ln_b1 = Ly.qkv_b1;
+            }
+#endif
+            launch_gemm(g, fold1 ? EPI_QKV_LN : EPI_QKV, s);
         }
         {
             ProfScope ps(e, KC_ATTN, s);
@@ -319,6 +331,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             GemmParams g{};
             g.A = e->hid2; g.lda = e->hid; g.W = Ly.down_w; g.ldw = e->hid; g.M = M; g.N = d; g.K = e->hid;
             g.bias = Ly.down_b; g.resid = e->x; g.ldr = d;
+            g.stats_out = (fold1 && l + 1 < e->L) ? e->ln_stats : nullptr;
             launch_gemm(g, EPI_BIAS_RESID, s);
         }
         if (l == 0) if (int rc = capture(e, "blk0_mlp", e->x, (size_t)M * d, s)) return rc;
@@ -384,9 +397,14 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     if (const char* fd = getenv("TLD_FUSE_DWCONV")) e->fuse_dwconv = atoi(fd) != 0;
     if (const char* sl = getenv("TLD_SHARE_L0")) e->share_l0 = atoi(sl) != 0;
     if (const char* fl = getenv("TLD_FOLD_LN3")) e->fold_ln3 = atoi(fl) != 0;
+    if (const char* fl = getenv("TLD_FOLD_LN1")) e->fold_ln1 = atoi(fl) != 0;
 #ifndef TLD_RESID_BF16
-    e->fold_ln3 = false;               // the fold feeds the bf16 residual stream straight to the MFMA
+    e->fold_ln3 = false;               // the folds feed the bf16 residual stream straight to the MFMA
+    e->fold_ln1 = false;
 #endif
+    // LayerNorm-1 fold: needs the down projection's 96-column partial sums (d % 192 == 0, at most 8 groups) and a QKV
+    // width the 256-wide kernel takes for every batch size
+    e->fold_ln1 = e->fold_ln1 && gemm_resid_stat_slots(e->d) > 0 && (3 * e->d) % 256 == 0;
     // only where the fused up-projection and the statistics-writing row kernel exist
     e->fold_ln3 = e->fold_ln3 && e->fuse_dwconv && grid == 16 && e->hid % 256 == 0 && cross_row_supports_ln3_stats(e->d);
     *out = e;
@@ -456,6 +474,31 @@ int tld_engine_finalize_weights(tld_engine* e) {
         if (int rc = upload_f32(e, LK("mlp.mlp.3.bias"), &Ly.down_b, d)) return rc;
         if (int rc = upload_f32(e, LK("norm1.weight"), &Ly.n1_w, d)) return rc;
         if (int rc = upload_f32(e, LK("norm1.bias"), &Ly.n1_b, d)) return rc;
+        if (e->fold_ln1) {
+            const std::vector<float>& W = e->host[LK("self_attention.qkv_linear.weight")].data;   // [3d][d]
+            const std::vector<float>& g1 = e->host[LK("norm1.weight")].data;
+            const std::vector<float>& be = e->host[LK("norm1.bias")].data;
+            std::vector<uint16_t> wf((size_t)(3 * d * d));
+            std::vector<float> c1((size_t)(3 * d)), b1((size_t)(3 * d));
+            for (int64_t n = 0; n < 3 * d; ++n) {
+                double sc = 0.0, sb = 0.0;
+                for (int64_t k2 = 0; k2 < d; ++k2) {
+                    const float w = W[(size_t)(n * d + k2)];
+                    const uint16_t q = f32_to_bf16_rne(g1[(size_t)k2] * w);
+                    wf[(size_t)(n * d + k2)] = q;
+                    uint32_t u = (uint32_t)q << 16; float qf; memcpy(&qf, &u, 4);
+                    sc += qf; sb += (double)be[(size_t)k2] * w;
+                }
+                c1[(size_t)n] = (float)sc; b1[(size_t)n] = (float)sb;
+            }
+            if (int rc = dev_alloc(e, &Ly.qkv_wf, wf.size())) return rc;
+            if (int rc = dev_alloc(e, &Ly.qkv_c1, c1.size())) return rc;
+            if (int rc = dev_alloc(e, &Ly.qkv_b1, b1.size())) return rc;
+            HIP_TRY(hipMemcpy(Ly.qkv_wf, wf.data(), wf.size() * 2, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(Ly.qkv_c1, c1.data(), c1.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(Ly.qkv_b1, b1.data(), b1.size() * 4, hipMemcpyHostToDevice));
+            e->weight_bytes += (int64_t)wf.size() * 2 + (int64_t)c1.size() * 8;
+        }
         if (int rc = upload_f32(e, LK("norm2.weight"), &Ly.n2_w, d)) return rc;
         if (int rc = upload_f32(e, LK("norm2.bias"), &Ly.n2_b, d)) return rc;
         if (int rc = upload_f32(e, LK("norm3.weight"), &Ly.n3_w, d)) return rc;
@@ -527,6 +570,7 @@ int tld_engine_finalize_weights(tld_engine* e) {
     if (int rc = dev_alloc(e, &e->x_half, (M + 1) / 2 * d)) return rc;
     if (int rc = dev_alloc(e, &e->xn, M * d)) return rc;
     if (int rc = dev_alloc(e, &e->row_stats, M + 256)) return rc;
+    if (int rc = dev_alloc(e, &e->ln_stats, (M + 256) * kLnSlots)) return rc;
     if (int rc = dev_alloc(e, &e->qk, M * 2 * d)) return rc;
     if (int rc = dev_alloc(e, &e->vt, M * d)) return rc;
     if (int rc = dev_alloc(e, &e->att, M * d)) return rc;

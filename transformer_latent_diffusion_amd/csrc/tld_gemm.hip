@@ -78,6 +78,8 @@ struct G256P : G256<BN> {
     static constexpr int STAGES = 2;
     static constexpr int STAGE_BYTES = G256<BN>::A_BYTES + G256<BN>::B_BYTES;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    // EPI_QKV_LN: behind the two stages, the tile's raw row partial sums (256 x 64 B, DMA) and the reduced (mean, rstd)
+    static constexpr int LN_RAW = LDS_BYTES, LN_ST = LN_RAW + 256 * 8 * kLnSlots, QKVLN_LDS = LN_ST + 256 * 8;
     static constexpr int IMG_PITCH = 520;            // fused depthwise epilogue: bytes per token row of the LDS image (512 + 8)
     static constexpr int IMG_BYTES = 256 * IMG_PITCH;
     static constexpr int ROWSTAT_OFF = IMG_BYTES;    // folded LayerNorm-3: the tile's 256 (mean, rstd) pairs, behind the image
@@ -88,6 +90,7 @@ struct G256P : G256<BN> {
 template <int BN, int EPI>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks) {
     using G = G256P<BN>;
+    constexpr bool IS_QKV = EPI == EPI_QKV || EPI == EPI_QKV_LN, LN = EPI == EPI_QKV_LN;
     static_assert(8 * G::SCRATCH <= G::STAGE_BYTES, "epilogue scratch must fit in one stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         // the kernel from 245 to 213 VGPRs and 111 -> 110 us.
         constexpr bool swapped = EPI != EPI_F32;
         bool v_tile = false;
-        if constexpr (EPI == EPI_QKV) v_tile = n0 >= 2 * p.d;
+        if constexpr (IS_QKV) v_tile = n0 >= 2 * p.d;
 
         f32x16 acc[G::TM][G::TN];
 #pragma unroll
@@ -242,6 +245,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 stamp(k, 1);
                 __builtin_amdgcn_s_barrier();      // everybody's; stage (g+1)&1 (operands or epilogue scratch) is idle
                 stamp(k, 2);
+                if constexpr (LN) {
+                    // folded LayerNorm-1: the tile's 256 rows of partial sums (64 B each) travel by DMA into LDS behind
+                    // the stages while the K loop runs; two 1-KiB pieces (16 rows each) per wave
+                    if (k == 1) {
+                        static_assert(kLnSlots == 8, "one partial-sum row is 64 B");
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2) {
+                            const int piece = wid * 2 + q2;
+                            int row = m0 + piece * 16 + (lane >> 2);
+                            row = row < p.M ? row : p.M - 1;
+                            const char* src = reinterpret_cast<const char*>(p.ln_stats) + (size_t)row * 64 + (lane & 3) * 16;
+                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_RAW + piece * 1024), 16, 0, 0);
+                        }
+                    }
+                }
                 if constexpr (EPI == EPI_UP_DWCONV) {
                     // folded LayerNorm-3: the tile's 256 (mean, rstd) pairs travel by DMA into LDS behind the image while
                     // the K loop runs (K-step 1: every wave is past the previous tile's epilogue, which read them)
@@ -458,7 +476,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             } else if constexpr (EPI == EPI_BIAS_RESID) {
                 constexpr int P = 32 * 4 + 16;      // one 32x32 fp32 tile, padded pitch
 #pragma unroll
-                for (int i = 0; i < G::TM; ++i)
+                for (int i = 0; i < G::TM; ++i) {
+                    float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};   // row partials of the new residual
 #pragma unroll
                     for (int j = 0; j < G::TN; ++j) {
 #pragma unroll
@@ -482,15 +501,82 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                 float4 o = rs_load4(px);
                                 o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
                                 rs_store4(px, o);
+                                if constexpr (G::WCOLS == 96) {          // (LayerNorm-1 fold: 96-column groups only)
+                                    const float r0 = rs_round(o.x), r1 = rs_round(o.y), r2 = rs_round(o.z), r3 = rs_round(o.w);
+                                    ps[itr] += (r0 + r1) + (r2 + r3);
+                                    pq[itr] = fmaf(r0, r0, fmaf(r1, r1, fmaf(r2, r2, fmaf(r3, r3, pq[itr]))));
+                                }
                             }
                         }
                     }
+                    if constexpr (G::WCOLS == 96) {
+                        if (p.stats_out) {
+                            // a row's 96 columns of this wave sit in 8 adjacent lanes: three DPP steps, lane (ch == 0) writes
+                            const int slot = (n0 + wn * G::WCOLS) / 96;
+#pragma unroll
+                            for (int itr = 0; itr < 4; ++itr) {
+                                float a = ps[itr], q2 = pq[itr];
+                                a = dpp_add<0xB1>(a); q2 = dpp_add<0xB1>(q2);
+                                a = dpp_add<0x4E>(a); q2 = dpp_add<0x4E>(q2);
+                                a = dpp_add<0x141>(a); q2 = dpp_add<0x141>(q2);
+                                const int row = row0 + i * 32 + itr * 8 + (lane >> 3);
+                                if ((lane & 7) == 0 && row < p.M && slot < kLnSlots) p.stats_out[(size_t)row * kLnSlots + slot] = make_float2(a, q2);
+                            }
+                        }
+                    }
+                }
             } else if constexpr (G::WCOLS == 64) {
                 // lane-derived values re-materialised per tile: otherwise every address expression of this epilogue is
                 // hoisted out of the tile loop and lives (or spills) across the K loops
                 int e_lane = lane, e_l31 = l31, e_hi = hi;
                 asm volatile("" : "+v"(e_lane), "+v"(e_l31), "+v"(e_hi));
-                const bool to_vt = (EPI == EPI_QKV) && v_tile;
+                if constexpr (LN) {
+                    // (mean, rstd) of the tile's rows from the partial sums: two threads per row, four slots each
+                    {
+                        const int tid = wid * 64 + e_lane;
+                        const int s0 = (tid & 1) * 4;
+                        const float4* raw = reinterpret_cast<const float4*>(smem + G::LN_RAW + (tid >> 1) * 64 + s0 * 8);
+                        float su = 0.f, sq = 0.f;
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2)
+                            if (s0 + 2 * q2 < p.ln_slots) {
+                                const float4 v = raw[q2];
+                                su += v.x + v.z; sq += v.y + v.w;
+                            }
+                        su = dpp_add<0xB1>(su); sq = dpp_add<0xB1>(sq);          // the row's other half sits in lane ^ 1
+                        const float inv_k = 1.0f / (float)p.K;
+                        const float mu = su * inv_k;
+                        const float var = fmaxf(fmaf(sq, inv_k, -mu * mu), 0.f);
+                        if (!(tid & 1))
+                            reinterpret_cast<float2*>(smem + G::LN_ST)[tid >> 1] = make_float2(mu, __builtin_amdgcn_rsqf(var + kLnEps));
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                    // y = rstd (acc - mean c1) + b1 in place: lane = token row (all tiles are swapped), column constants
+                    // fetched once per 4 columns
+                    float rs[G::TM], nm[G::TM];
+#pragma unroll
+                    for (int i = 0; i < G::TM; ++i) {
+                        const float2 st = reinterpret_cast<const float2*>(smem + G::LN_ST)[wm * G::WROWS + i * 32 + e_l31];
+                        rs[i] = st.y; nm[i] = -st.y * st.x;
+                    }
+#pragma unroll
+                    for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const int cg = col0 + j * 32 + 8 * rq + 4 * e_hi < p.N ? col0 + j * 32 + 8 * rq + 4 * e_hi : 0;
+                            const float4 c4 = *reinterpret_cast<const float4*>(p.ln_c1 + cg);
+                            const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b1 + cg);
+#pragma unroll
+                            for (int i = 0; i < G::TM; ++i) {
+                                acc[i][j][rq * 4 + 0] = fmaf(rs[i], acc[i][j][rq * 4 + 0], fmaf(nm[i], c4.x, b4.x));
+                                acc[i][j][rq * 4 + 1] = fmaf(rs[i], acc[i][j][rq * 4 + 1], fmaf(nm[i], c4.y, b4.y));
+                                acc[i][j][rq * 4 + 2] = fmaf(rs[i], acc[i][j][rq * 4 + 2], fmaf(nm[i], c4.z, b4.z));
+                                acc[i][j][rq * 4 + 3] = fmaf(rs[i], acc[i][j][rq * 4 + 3], fmaf(nm[i], c4.w, b4.w));
+                            }
+                        }
+                }
+                const bool to_vt = IS_QKV && v_tile;
                 if (!to_vt) {
                     // one 32-row x 64-col bf16 slab per pass: 128-B pitch, 16-B chunks XOR-swizzled with (row & 7)
                     constexpr int P = 128;
@@ -521,7 +607,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             const int row = row0 + i * 32 + rl, col = col0 + ch * 8;
                             if (row < p.M && col < p.N) {
                                 u32x4* dst = reinterpret_cast<u32x4*>(p.out_bf16 + (size_t)row * p.ldo + col);
-                                if constexpr (EPI == EPI_QKV) *dst = v;      // attention re-reads q|k from L2
+                                if constexpr (IS_QKV) *dst = v;              // attention re-reads q|k from L2
                                 else TLD_STORE(dst, v);
                             }
                         }
@@ -586,7 +672,8 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
         pg.xcd_ngroups = 2;
 #define TLD_L256P(E)                                                                                  \
     do {                                                                                              \
-        constexpr int lds = (E) == EPI_UP_DWCONV && G::UPDW_LDS > G::LDS_BYTES ? G::UPDW_LDS : G::LDS_BYTES;     \
+        constexpr int lds = (E) == EPI_UP_DWCONV && G::UPDW_LDS > G::LDS_BYTES ? G::UPDW_LDS                     \
+                            : ((E) == EPI_QKV_LN ? G::QKVLN_LDS : G::LDS_BYTES);                      \
         static bool once = false;                                                                     \
         if (!once) {                                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E>),                \
@@ -601,6 +688,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
         switch (epilogue) {
             case EPI_F32: TLD_L256P(EPI_F32); break;
             case EPI_QKV: TLD_L256P(EPI_QKV); break;
+            case EPI_QKV_LN: TLD_L256P(EPI_QKV_LN); break;
             case EPI_BIAS_BF16: TLD_L256P(EPI_BIAS_BF16); break;
             case EPI_BIAS_RESID: TLD_L256P(EPI_BIAS_RESID); break;
             case EPI_UP_DWCONV: if constexpr (BN == 256) { TLD_L256P(EPI_UP_DWCONV); } break;
@@ -622,8 +710,11 @@ int choose_bn(long M, long N, int epilogue) {
     static const char* force = getenv("TLD_GEMM_BN");             // experiment knob
     int bn = narrow ? 128 : 256;
     if (narrow && epilogue == EPI_BIAS_RESID && N % 192 == 0 && (ntm * (N / 192)) % 256 == 0) bn = 192;
-    // down projection at the bench size: 256 x 384 tiles make N = 768 ONE round of 256 workgroups (176 -> 155 us)
+    // down projection at the bench size: 256 x 384 tiles make N = 768 ONE round of 256 workgroups (176 -> 155 us);
+    // any other batch size of that width uses 192-wide tiles, never 128 / 256: both 192 and 384 give 96-column wave
+    // tiles, which is what the LayerNorm-1 partial sums are defined on (results must not depend on the batch size)
     static const bool wide = !(getenv("TLD_DOWN_BN384") && atoi(getenv("TLD_DOWN_BN384")) == 0);     // A/B knob
+    if (epilogue == EPI_BIAS_RESID && N % 192 == 0) bn = 192;
     if (wide && epilogue == EPI_BIAS_RESID && N % 384 == 0 && (ntm * (N / 384)) % 256 == 0) bn = 384;
     if (force) bn = atoi(force);
     if (epilogue == EPI_UP_DWCONV) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
@@ -633,6 +724,10 @@ int choose_bn(long M, long N, int epilogue) {
     return bn;
 }
 }  // namespace
+
+int gemm_resid_stat_slots(int N) {
+    return (N % 192 == 0 && N / 96 <= kLnSlots && !getenv("TLD_GEMM_BN")) ? N / 96 : 0;
+}
 
 void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
 #ifdef TLD_DBG_EPI

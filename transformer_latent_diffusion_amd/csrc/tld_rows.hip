@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) { e[j].x -= mean2; e[j].y -= mean2; q += e[j].x * e[j].x + e[j].y * e[j].y; }
         const float rstd2 = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
+        float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = j * 128 + 2 * lane;
@@ -124,6 +125,13 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
             o.x = e[j].x * rstd2 * g.x + bb.x + pe.x;
             o.y = e[j].y * rstd2 * g.y + bb.y + pe.y;
             rs_store2(p.tok + (size_t)row * d + n, o);
+            const float r0 = rs_round(o.x), r1 = rs_round(o.y);
+            ssum += r0 + r1;
+            ssq = fmaf(r0, r0, fmaf(r1, r1, ssq));
+        }
+        if (p.stats_out) {       // LayerNorm-1 statistics of block 0, consumed by its QKV GEMM epilogue (slots come in pairs)
+            ssum = wave_sum(ssum); ssq = wave_sum(ssq);
+            if (lane == 0) *reinterpret_cast<float4*>(p.stats_out + (size_t)row * kLnSlots) = make_float4(ssum, ssq, 0.f, 0.f);
         }
     }
 }
