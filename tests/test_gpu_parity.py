@@ -254,7 +254,7 @@ print("REL", rel_rms(out, g["x0"]))
 """
 
 
-@pytest.mark.parametrize("knobs", [{"TLD_FOLD_LN3": "0"}, {"TLD_FUSE_DWCONV": "0"}, {"TLD_DOWN_BN384": "0"},
+@pytest.mark.parametrize("knobs", [{"TLD_FOLD_LN3": "0"}, {"TLD_FOLD_LN1": "0"}, {"TLD_FUSE_DWCONV": "0"}, {"TLD_DOWN_BN384": "0"},
                                    {"TLD_CROSS_Q4": "0", "TLD_LN_Q4": "0"}, {"TLD_SHARE_L0": "0", "TLD_ATTN_8W": "1"}])
 def test_fallback_paths_vs_golden(knobs):
     """The A/B switches select older code paths that stay in the tree (and serve other shapes): each must still
