@@ -79,7 +79,7 @@ struct G256P : G256<BN> {
     static constexpr int STAGE_BYTES = G256<BN>::A_BYTES + G256<BN>::B_BYTES;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
     // EPI_QKV_LN: behind the two stages, the tile's raw row partial sums (256 x 64 B, DMA) and the reduced (mean, rstd)
-    static constexpr int LN_RAW = LDS_BYTES, LN_ST = LN_RAW + 256 * 8 * kLnSlots, QKVLN_LDS = LN_ST + 256 * 8;
+    static constexpr int LN_RAW = LDS_BYTES, LN_ST = LN_RAW + 256 * 8 * kLnSlots, LN_CB = LN_ST + 256 * 8, QKVLN_LDS = LN_CB + 2048;   // + c1 | b1 of the tile's columns
     static constexpr int IMG_PITCH = 520;            // fused depthwise epilogue: bytes per token row of the LDS image (512 + 8)
     static constexpr int IMG_BYTES = 256 * IMG_PITCH;
     static constexpr int ROWSTAT_OFF = IMG_BYTES;    // folded LayerNorm-3: the tile's 256 (mean, rstd) pairs, behind the image
@@ -257,6 +257,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             row = row < p.M ? row : p.M - 1;
                             const char* src = reinterpret_cast<const char*>(p.ln_stats) + (size_t)row * 64 + (lane & 3) * 16;
                             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_RAW + piece * 1024), 16, 0, 0);
+                        }
+                        if (wid < 2) {                                    // wave 0: c1, wave 1: b1 of the tile's columns (4 per lane)
+                            int col = n0 + lane * 4;
+                            col = col < p.N ? col : 0;
+                            const float* src = (wid == 0 ? p.ln_c1 : p.ln_b1) + col;
+                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_CB + wid * 1024), 16, 0, 0);
                         }
                     }
                 }
@@ -564,9 +570,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     for (int j = 0; j < G::TN; ++j)
 #pragma unroll
                         for (int rq = 0; rq < 4; ++rq) {
-                            const int cg = col0 + j * 32 + 8 * rq + 4 * e_hi < p.N ? col0 + j * 32 + 8 * rq + 4 * e_hi : 0;
-                            const float4 c4 = *reinterpret_cast<const float4*>(p.ln_c1 + cg);
-                            const float4 b4 = *reinterpret_cast<const float4*>(p.ln_b1 + cg);
+                            const int cl = wn * G::WCOLS + j * 32 + 8 * rq + 4 * e_hi;         // column inside the tile
+                            const float4 c4 = *reinterpret_cast<const float4*>(smem + G::LN_CB + cl * 4);
+                            const float4 b4 = *reinterpret_cast<const float4*>(smem + G::LN_CB + 1024 + cl * 4);
 #pragma unroll
                             for (int i = 0; i < G::TM; ++i) {
                                 acc[i][j][rq * 4 + 0] = fmaf(rs[i], acc[i][j][rq * 4 + 0], fmaf(nm[i], c4.x, b4.x));
