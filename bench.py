@@ -176,7 +176,7 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = total * args.steps / dt
         line = {
-            "metric": "images/sec (256px, 35-step CFG sampling), denoiser only",
+            "metric": f"images/sec ({8 * S}px, 35-step CFG sampling), denoiser only",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
