@@ -52,7 +52,9 @@ enum {
     TLD_ERR_HIP = 5           /* a HIP runtime call failed */
 };
 
-/* Denoiser(**asdict(cfg)) -- tld/denoiser.py:85-114, tld/diffusion.py:145 */
+/* Denoiser(**asdict(cfg)) -- tld/denoiser.py:85-114, tld/diffusion.py:145
+ * (No entry point changes the calling thread's current HIP device: each one switches to cfg.device_id
+ * for its own duration and restores the previous device before returning.) */
 TLD_API int tld_engine_create(const tld_config* cfg, tld_engine** out);
 
 /* Denoiser.load_state_dict, one entry at a time -- tld/diffusion.py:152-153.
@@ -110,9 +112,12 @@ TLD_API int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilog
 /* Live per-kernel-class timing with HIP events recorded on the launch stream around every launch
  * of the selected classes (bit k of class_mask).  Classes: 0 gemm_qkv, 1 gemm_up, 2 gemm_down,
  * 3 attention, 4 cross_row, 5 dwconv_gelu, 6 layernorm, 7 embed, 8 tail, 9 update, 10 conditioning.
- * set_profile clears previously recorded events; get_profile synchronises the device and returns
- * the summed elapsed time and the number of launches of one class since set_profile. */
+ * set_profile forgets previously recorded timings; get_profile synchronises the device and returns
+ * the summed elapsed time and the number of launches of one class since set_profile.
+ * profile_reserve pre-creates `launches` event pairs for one class so that a timed region records into
+ * existing events only (no hipEventCreate between the caller's fences). */
 TLD_API int tld_engine_set_profile(tld_engine* e, uint32_t class_mask);
+TLD_API int tld_engine_profile_reserve(tld_engine* e, int32_t kclass, int64_t launches);
 TLD_API int tld_engine_get_profile(tld_engine* e, int32_t kclass, double* total_ms, int64_t* launches);
 
 /* bytes of packed weights resident on the device */

@@ -21,6 +21,12 @@ Fixtures:
   g7_100m_512px.npz       BASELINE config C3 shape: 100M model with image_size=64 (N=1024 tokens), forward B=1
   g8_100m_1024px.npz      BASELINE config C4 shape: image_size=128 (N=4096 tokens), forward B=1 (bf16 path; the
                           reference has no fp8 and no pos-embed interpolation code -- SURVEY.md section 0.5)
+  g9_ln_stress.npz        d=768, L=2 model whose residual rows carry a large common offset (|row mean| / row std ~ 4, 28 and 85 at
+                          the first norm1): stresses LayerNorm statistics (the engine's folded LayerNorm-1 / -3 paths)
+  g11_100m_512px_traj.npz C3 sampler: 100M model at image_size=64, 35-step CFG=6 DPM-2M end latent, B=1
+
+Usage: python oracle/gen_golden.py            (all fixtures)
+       python oracle/gen_golden.py g9 g11     (only the named ones; names are matched by prefix)
 """
 import os
 import sys
@@ -238,14 +244,75 @@ def schedule_fixture():
     save("g6_schedule.npz", **d)
 
 
+LN_STRESS_KEY = "denoiser_trans_block.patchify_and_embed.4.bias"
+
+
+def ln_stress_fixture():
+    """Rows of the residual stream with a large common offset: the synthetic weights plus a constant added to the
+    affine bias of the embedding LayerNorm (every feature of every token row is shifted; the blocks add O(1)
+    updates, so the offset survives to every LayerNorm of every block).  Records the offset / spread ratio the
+    reference actually sees at the input of each block's norm1."""
+    cfg = config_100m(); cfg.n_layers = 2
+    sd0 = synth_state_dict(cfg, 9)
+    x, sigma, label = inputs(cfg, 2, 99)
+    d = dict(cfg=cfg_arr(cfg), weight_seed=np.int64(9), weight_checksum=np.array(state_dict_checksum(sd0)),
+             shift_key=np.array(LN_STRESS_KEY), x=x.numpy(), sigma=sigma.numpy(), label=label.numpy())
+    for tag, shift in (("mod", 6.0), ("big", 40.0), ("huge", 120.0)):
+        sd = dict(sd0)
+        sd[LN_STRESS_KEY] = (np.asarray(sd0[LN_STRESS_KEY]) + np.float32(shift)).astype(np.float32)
+        m = Denoiser(**asdict(cfg))
+        m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+        m.eval()
+        ratios = []
+        hooks = [blk.norm1.register_forward_hook(
+            lambda mod, inp, out: ratios.append(float((inp[0].mean(-1).abs() / inp[0].std(-1)).median())))
+            for blk in m.denoiser_trans_block.decoder_blocks]
+        x0 = m(x, sigma, label)
+        for h in hooks:
+            h.remove()
+        d[f"{tag}_shift"] = np.float32(shift)
+        d[f"{tag}_x0"] = x0.numpy()
+        d[f"{tag}_mean_over_std"] = np.array(ratios, dtype=np.float64)
+        print(f"ln stress {tag}: shift {shift}, median |row mean| / row std at norm1 inputs = {ratios}")
+    save("g9_ln_stress.npz", **d)
+
+
+def c3_traj_fixture():
+    cfg = config_100m(64)
+    m, ck = build_ref(cfg, 7)                   # same weights as g7
+    gen = DiffusionGenerator(m, FakeVAE(), torch.device("cpu"), torch.float32)
+    g = torch.Generator().manual_seed(111)
+    seeds = torch.randn(1, 4, 64, 64, generator=g)
+    labels = torch.randn(1, 768, generator=g) * 0.5
+    cap = {}
+    lat, rec = run_generate(gen, cap, labels=labels, n_iter=35, num_imgs=1, class_guidance=6.0,
+                            seeds=seeds.clone(), img_size=64, sharp_f=0.0, bright_f=0.0, exponent=1)
+    save("g11_100m_512px_traj.npz", cfg=cfg_arr(cfg), weight_seed=np.int64(7), weight_checksum=np.array(ck),
+         traj_seeds=seeds.numpy(), traj_labels=labels.numpy(), traj_n_iter=np.int64(35),
+         traj_class_guidance=np.float64(6.0), traj_latent=lat, traj_x0_first=rec["x0"][0])
+
+
+def _c4():
+    c4 = config_100m(); c4.n_layers = 1
+    return c4
+
+
+FIXTURES = {
+    "g1": lambda: forward_fixture("g1_tiny32_forward.npz", DenoiserConfig(image_size=32, n_channels=4), 1, 3, 11, stages=True),
+    "g2": sampler_fixture,
+    "g3": lambda: forward_fixture("g3_tiny16_forward.npz", DenoiserConfig(), 3, 4, 33),
+    "g4": lambda: forward_fixture("g4_wide1_forward.npz", _c4(), 4, 2, 44),
+    "g6": schedule_fixture,
+    "g5": big_fixture,
+    "g7": lambda: forward_fixture("g7_100m_512px.npz", config_100m(64), 7, 1, 77),
+    "g8": lambda: forward_fixture("g8_100m_1024px.npz", config_100m(128), 8, 1, 88),
+    "g9": ln_stress_fixture,
+    "g11": c3_traj_fixture,
+}
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    forward_fixture("g1_tiny32_forward.npz", DenoiserConfig(image_size=32, n_channels=4), 1, 3, 11, stages=True)
-    sampler_fixture()
-    forward_fixture("g3_tiny16_forward.npz", DenoiserConfig(), 3, 4, 33)
-    c4 = config_100m(); c4.n_layers = 1
-    forward_fixture("g4_wide1_forward.npz", c4, 4, 2, 44)
-    schedule_fixture()
-    big_fixture()
-    forward_fixture("g7_100m_512px.npz", config_100m(64), 7, 1, 77)
-    forward_fixture("g8_100m_1024px.npz", config_100m(128), 8, 1, 88)
+    want = sys.argv[1:]
+    for name, fn in FIXTURES.items():
+        if not want or any(name == w or w.startswith(name + "_") for w in want):
+            fn()

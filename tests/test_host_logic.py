@@ -67,6 +67,12 @@ def test_generator_shell_without_gpu_fails_loudly_and_checks_labels():
     assert torch.equal(x, ref)                                           # diffusion.py:108-118 on cpu
     s = torch.ones(2, 4, 16, 16, dtype=torch.float64)
     assert gen.initialize_image(s, 2, 16, 0).dtype == torch.float32      # seeds.to(device, model_dtype)
+    # the x_T the REFERENCE drew for seed=10 on its CPU path (captured by oracle/gen_golden.py): bit-exact
+    from conftest import load_golden
+    g2 = load_golden("g2_tiny32_sampler.npz")
+    gen32 = DiffusionGenerator(Denoiser(**asdict(DenoiserConfig(image_size=32, n_channels=4))), None,
+                               torch.device("cpu"), torch.float32)
+    assert np.array_equal(gen32.initialize_image(None, 2, 32, seed=10).numpy(), g2["seed10_xT"])
     with pytest.raises(RuntimeError):
         gen.generate(torch.zeros(2, 768), num_imgs=3, img_size=16, n_iter=5)   # labels/num_imgs mismatch
     if not torch.cuda.is_available():
@@ -95,6 +101,25 @@ def test_image_grid_and_pil():
     assert torch.equal(grid[:, 4:12, 4:12], imgs[0]) and torch.equal(grid[:, 16:24, 16:24], imgs[3])
     assert make_image_grid(imgs[:1], nrow=1).shape == (3, 8, 8)
     assert to_pil(grid).size == (28, 40)
+    # torchvision.utils.make_grid semantics (what diffusion.py:185 calls; torchvision is not installed here, so the
+    # expected layout is spelled out): xmaps = min(nrow, b), ymaps = ceil(b / xmaps), cell (H+pad, W+pad), image k at
+    # (pad + (k // xmaps) * (H+pad), pad + (k % xmaps) * (W+pad)), background pad_value = 0, a single image is
+    # returned as is.  generate_image_from_text uses nrow = int(sqrt(num_imgs)).
+    for b in (1, 4, 5, 9):
+        nrow = int(np.sqrt(b))
+        im = torch.rand(b, 3, 6, 5)
+        gr = make_image_grid(im, nrow=nrow, padding=4)
+        if b == 1:
+            assert torch.equal(gr, im[0]); continue
+        xm = min(nrow, b); ym = -(-b // xm)
+        exp = torch.zeros(3, ym * 10 + 4, xm * 9 + 4)
+        for k in range(b):
+            y0, x0 = 4 + (k // xm) * 10, 4 + (k % xm) * 9
+            exp[:, y0:y0 + 6, x0:x0 + 5] = im[k]
+        assert torch.equal(gr, exp), b
+    # ToPILImage semantics for float tensors: mul(255).byte() truncates
+    px = to_pil(torch.tensor([[[0.999, 0.5]], [[0.0, 1.0]], [[0.25, 2.0]]]).clamp(0, 1))
+    assert px.getpixel((0, 0)) == (254, 0, 63) and px.getpixel((1, 0)) == (127, 255, 255)
 
 
 def test_shard_bounds_cover_exactly():

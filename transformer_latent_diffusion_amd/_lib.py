@@ -21,7 +21,7 @@ KERNEL_CLASSES = ("gemm_qkv", "gemm_up", "gemm_down", "attention", "cross_row", 
 ABI_SYMBOLS = (
     "tld_engine_create", "tld_engine_load_tensor", "tld_engine_finalize_weights", "tld_denoiser_forward",
     "tld_sample", "tld_engine_set_debug", "tld_engine_read_stage", "tld_debug_gemm_bf16", "tld_debug_gemm_bench",
-    "tld_engine_set_profile", "tld_engine_get_profile", "tld_engine_weight_bytes", "tld_engine_destroy",
+    "tld_engine_set_profile", "tld_engine_profile_reserve", "tld_engine_get_profile", "tld_engine_weight_bytes", "tld_engine_destroy",
     "tld_last_error",
 )
 
@@ -68,6 +68,7 @@ def lib() -> C.CDLL:
     L.tld_debug_gemm_bf16.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     L.tld_debug_gemm_bench.argtypes = [i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]
     L.tld_engine_set_profile.argtypes = [vp, C.c_uint32]
+    L.tld_engine_profile_reserve.argtypes = [vp, i32, C.c_int64]
     L.tld_engine_get_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.tld_engine_weight_bytes.argtypes = [vp]
     L.tld_engine_weight_bytes.restype = C.c_int64

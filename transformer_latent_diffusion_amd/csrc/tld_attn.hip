@@ -354,7 +354,7 @@ void launch_attention(const bf16* qk, const bf16* vt, bf16* att, int batch, int 
     // 256-key chunks staged once per workgroup of 8 waves (256 query rows).  Measured alternative: 4-wave
     // workgroups, two per CU (staging overlapped with compute) -- 88 us vs 60 us per layer at C1, the K/V
     // chunk is then staged twice per head and the extra L2->LDS traffic costs more than the overlap buys.
-    static const bool one_wg = getenv("TLD_ATTN_8W") != nullptr;     // A/B knob: single 8-wave workgroup per CU
+    static const bool one_wg = getenv("TLD_ATTN_8W") && atoi(getenv("TLD_ATTN_8W")) != 0;     // A/B knob: single 8-wave workgroup per CU
     if (ntok == 256 && !one_wg) launch_attn1<8, 4, 2>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok % 256 == 0) launch_kt<8, 8>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 128) launch_kt<4, 4>(qk, vt, att, batch, ntok, heads, s);

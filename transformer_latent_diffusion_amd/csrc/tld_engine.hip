@@ -45,6 +45,20 @@ inline uint16_t f32_to_bf16_rne(float f) {
     return (uint16_t)(u >> 16);
 }
 
+// Every ABI entry point runs with the engine's device current and puts the caller's device back on exit: the
+// library never changes the calling thread's current HIP device (a model on cuda:1 used from a thread whose
+// current device is cuda:0 would otherwise silently redirect the caller's later allocations and launches).
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+        else if (prev < 0) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct HostTensor {
     std::vector<float> data;
     std::vector<int64_t> shape;
@@ -113,8 +127,11 @@ struct tld_engine {
     std::map<std::string, float*> stages;
 
     // per-class event profiling
+    // (event pairs come from a per-class pool that set_profile / profile_reserve fill OUTSIDE any timed region;
+    // a launch only records into the next free pair)
     uint32_t prof_mask = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[KC_COUNT];
+    size_t prof_used[KC_COUNT] = {};
 };
 
 namespace {
@@ -181,14 +198,21 @@ int ensure_rows_capacity(tld_engine* e, int64_t n) {
 }
 
 struct ProfScope {
-    tld_engine* e; int cls; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
+    tld_engine* e; int cls; hipStream_t s; hipEvent_t b = nullptr; bool on;
     ProfScope(tld_engine* e_, int cls_, hipStream_t s_) : e(e_), cls(cls_), s(s_) {
         on = (e->prof_mask >> cls) & 1u;
-        if (on) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, s); }
+        if (!on) return;
+        auto& pool = e->prof_ev[cls];
+        if (e->prof_used[cls] == pool.size()) {          // pool exhausted (no tld_engine_profile_reserve): grow here
+            hipEvent_t a2 = nullptr, b2 = nullptr;
+            hipEventCreate(&a2); hipEventCreate(&b2);
+            pool.emplace_back(a2, b2);
+        }
+        const auto& pr = pool[e->prof_used[cls]++];
+        b = pr.second;
+        hipEventRecord(pr.first, s);
     }
-    ~ProfScope() {
-        if (on) { hipEventRecord(b, s); e->prof_ev[cls].emplace_back(a, b); }
-    }
+    ~ProfScope() { if (on) hipEventRecord(b, s); }
 };
 
 int capture(tld_engine* e, const char* name, const resid_t* src, size_t count, hipStream_t s) {
@@ -383,7 +407,16 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (c->device_id < 0 || c->device_id >= ndev) return fail(TLD_ERR_INVALID, "device_id %d out of range (%d devices)", c->device_id, ndev);
-    HIP_TRY(hipSetDevice(c->device_id));
+    {   // the row kernels keep per-workgroup tables in dynamic LDS (no opt-in above 64 KiB is requested for them)
+        const long d = c->embed_dim, H = d / 64;
+        const long embed_lds = (pd * d + (long)pd * pd) * 4, tail_lds = pd * d * 4, cross_lds = (H * d + 2 * d + H) * 4;
+        const long lim = 64 * 1024;
+        if (embed_lds > lim || tail_lds > lim || cross_lds > lim)
+            return fail(TLD_ERR_INVALID, "embed_dim=%d with patch_dim=%d needs %ld / %ld / %ld bytes of LDS in the embed / "
+                        "out-proj / cross-attention row kernels (limit %ld each): reduce patch_size*patch_size*n_channels "
+                        "or embed_dim", c->embed_dim, pd, embed_lds, tail_lds, cross_lds, lim);
+    }
+    DeviceGuard dg(c->device_id);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -428,7 +461,7 @@ int tld_engine_load_tensor(tld_engine* e, const char* key, const void* host_ptr,
 int tld_engine_finalize_weights(tld_engine* e) {
     if (!e) return fail(TLD_ERR_INVALID, "null engine");
     if (e->finalized) return TLD_OK;
-    HIP_TRY(hipSetDevice(e->cfg.device_id));
+    DeviceGuard dg(e->cfg.device_id);
     const int64_t d = e->d, ne = e->ne, pd = e->pd, hid = e->hid, N = e->ntok, text = e->text;
     const int64_t cpp = pd;   // C*p*p
 #define UP32(key, field, n) if (int rc = upload_f32(e, key, &e->field, (n))) return rc;
@@ -597,6 +630,7 @@ int tld_engine_set_debug(tld_engine* e, int32_t enable) {
 
 int tld_engine_read_stage(tld_engine* e, const char* name, float* host_out, int64_t numel) {
     if (!e || !name || !host_out) return fail(TLD_ERR_INVALID, "null argument");
+    DeviceGuard dg(e->cfg.device_id);
     HIP_TRY(hipDeviceSynchronize());
     const float* src = nullptr;
     if (!strcmp(name, "cond_y")) src = e->c_y;
@@ -615,6 +649,7 @@ int tld_denoiser_forward(tld_engine* e, const void* x, const void* noise, const 
     if (!e->finalized) return fail(TLD_ERR_STATE, "weights not finalized");
     if (batch <= 0 || batch > e->cfg.max_batch) return fail(TLD_ERR_INVALID, "batch %d outside (0, max_batch=%d]", batch, e->cfg.max_batch);
     if (io_dtype < 0 || io_dtype > 2) return fail(TLD_ERR_INVALID, "bad io_dtype %d", io_dtype);
+    DeviceGuard dg(e->cfg.device_id);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const float* xin = static_cast<const float*>(x);
     float* o = static_cast<float*>(out);
@@ -647,6 +682,7 @@ int tld_sample(tld_engine* e, const void* x_T, const void* labels, const float* 
     if (batch <= 0 || 2 * batch > e->cfg.max_batch)
         return fail(TLD_ERR_INVALID, "sampler batch %d needs max_batch >= %d (have %d)", batch, 2 * batch, e->cfg.max_batch);
     if (n_levels < 2) return fail(TLD_ERR_INVALID, "need at least two noise levels");
+    DeviceGuard dg(e->cfg.device_id);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const int B = batch, B2 = 2 * batch, T = n_levels + B + 1;
     if (int rc = ensure_cond_capacity(e, T)) return rc;
@@ -779,26 +815,37 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
 
 int tld_engine_set_profile(tld_engine* e, uint32_t class_mask) {
     if (!e) return fail(TLD_ERR_INVALID, "null engine");
-    for (int k = 0; k < KC_COUNT; ++k) {
-        for (auto& ev : e->prof_ev[k]) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
-        e->prof_ev[k].clear();
-    }
+    for (int k = 0; k < KC_COUNT; ++k) e->prof_used[k] = 0;       // recorded pairs are forgotten, the pool is kept
     e->prof_mask = class_mask;
+    return TLD_OK;
+}
+
+int tld_engine_profile_reserve(tld_engine* e, int32_t kclass, int64_t launches) {
+    if (!e) return fail(TLD_ERR_INVALID, "null engine");
+    if (kclass < 0 || kclass >= KC_COUNT || launches < 0) return fail(TLD_ERR_INVALID, "bad kernel class %d / count", kclass);
+    DeviceGuard dg(e->cfg.device_id);
+    auto& pool = e->prof_ev[kclass];
+    while ((int64_t)pool.size() < launches) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+        pool.emplace_back(a, b);
+    }
     return TLD_OK;
 }
 
 int tld_engine_get_profile(tld_engine* e, int32_t kclass, double* total_ms, int64_t* launches) {
     if (!e || !total_ms || !launches) return fail(TLD_ERR_INVALID, "null argument");
     if (kclass < 0 || kclass >= KC_COUNT) return fail(TLD_ERR_INVALID, "bad kernel class %d", kclass);
+    DeviceGuard dg(e->cfg.device_id);
     HIP_TRY(hipDeviceSynchronize());
     double tot = 0.0;
-    for (auto& ev : e->prof_ev[kclass]) {
+    for (size_t i = 0; i < e->prof_used[kclass]; ++i) {
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+        HIP_TRY(hipEventElapsedTime(&ms, e->prof_ev[kclass][i].first, e->prof_ev[kclass][i].second));
         tot += ms;
     }
     *total_ms = tot;
-    *launches = (int64_t)e->prof_ev[kclass].size();
+    *launches = (int64_t)e->prof_used[kclass];
     return TLD_OK;
 }
 
@@ -806,7 +853,7 @@ int64_t tld_engine_weight_bytes(const tld_engine* e) { return e ? e->weight_byte
 
 int tld_engine_destroy(tld_engine* e) {
     if (!e) return TLD_OK;
-    (void)hipSetDevice(e->cfg.device_id);
+    DeviceGuard dg(e->cfg.device_id);
     (void)hipDeviceSynchronize();
     for (int k = 0; k < KC_COUNT; ++k)
         for (auto& ev : e->prof_ev[k]) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }

@@ -113,7 +113,7 @@ class Denoiser:
     # ---- engine management ---------------------------------------------------------------------------
     def _drop_engine(self):
         if self._engine is not None:
-            _lib.lib().tld_engine_destroy(self._engine)
+            _lib.lib().tld_engine_destroy(self._engine)       # (the C ABI restores the caller's current device)
         self._engine = None
         self._engine_batch = 0
 
@@ -235,6 +235,11 @@ class Denoiser:
         for c in classes:
             mask |= 1 << _lib.KERNEL_CLASSES.index(c)
         _lib.check(_lib.lib().tld_engine_set_profile(self._engine, mask), "tld_engine_set_profile")
+
+    def reserve_profile(self, cls: str, launches: int):
+        """Pre-create the event pairs ``launches`` timed launches of class ``cls`` will record into."""
+        _lib.check(_lib.lib().tld_engine_profile_reserve(self._engine, _lib.KERNEL_CLASSES.index(cls), int(launches)),
+                   "tld_engine_profile_reserve")
 
     def get_profile(self, cls: str):
         ms, n = C.c_double(), C.c_int64()

@@ -77,13 +77,20 @@ class DiffusionGenerator:
         return out.to(self.model_dtype)
 
     def initialize_image(self, seeds, num_imgs, img_size, seed):
-        """Initial noise: a ``torch.Generator`` on ``self.device`` seeded with ``seed`` or the caller's
-        ``seeds`` tensor (diffusion.py:105-120)."""
+        """Initial noise (diffusion.py:105-120): the caller's ``seeds`` tensor, or ``torch.randn`` from a
+        generator seeded with ``seed``.
+
+        The generator lives on the HOST (``torch.Generator('cpu')``), whatever ``self.device`` is: parity is
+        stated against the reference's CPU path, whose generator is the CPU one (``device`` = cpu there), so
+        ``seed=`` reproduces the reference's x_T bit for bit (tests/golden g2 ``seed10_xT``); it also makes the
+        noise independent of the number of ranks a batch is later sharded over.  The draw is one small tensor
+        per call, moved to the device once."""
         if seeds is None:
-            generator = torch.Generator(device=self.device)
+            generator = torch.Generator(device="cpu")
             generator.manual_seed(seed)
-            return torch.randn(num_imgs, self.model.n_channels, img_size, img_size, dtype=self.model_dtype,
-                               device=self.device, generator=generator)
+            x = torch.randn(num_imgs, self.model.n_channels, img_size, img_size, dtype=self.model_dtype,
+                            generator=generator)
+            return x.to(self.device)
         return seeds.to(self.device, self.model_dtype)
 
 

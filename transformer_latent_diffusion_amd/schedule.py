@@ -24,8 +24,11 @@ def _torch_arange_f32(size: int, step: float, vec: int = 8) -> np.ndarray:
     ATen fills the range in pairs of 8-lane vectors: each vector's base is ``float32(step * idx)``
     and lane j holds ``float32(float64(base) + j * step)``; the tail shorter than two vectors is
     ``float32(step * idx)`` per element.  The two forms differ by one float32 ulp at a few indices
-    (first at n_iter=40, index 31); reproducing the vector form keeps the schedule bit-identical to
-    the reference's on AVX2/AVX-512 hosts (pinned by tests/golden/g6_schedule.npz).
+    (first at n_iter=40, index 31); reproducing the 8-lane vector form keeps the schedule bit-identical
+    to what the reference computed on the AVX2 ATen build the fixtures were captured with
+    (tests/golden/g6_schedule.npz).  ``vec`` is the lane count of ``Vectorized<float>``: an AVX-512 ATen
+    build uses 16, where the reference's own schedule differs from the fixture by at most 1 float32 ulp at
+    a few indices -- harmless (sigma only feeds fp32 scalars), but the bit-exact claim is per ISA.
     """
     out = np.empty(size, dtype=np.float32)
     i = 0
