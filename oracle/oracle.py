@@ -56,6 +56,7 @@ def lib() -> C.CDLL:
     L.tld_o_sample.argtypes = [C.c_void_p, fp, fp, C.c_int, dp, C.c_int, C.c_double, C.c_int,
                                C.c_double, C.c_double, fp, fp, fp]
     L.tld_o_num_threads.restype = C.c_int
+    L.tld_o_set_num_threads.argtypes = [C.c_int]
     _LIB = L
     return L
 
@@ -131,6 +132,10 @@ class OracleDenoiser:
                            len(nl), float(class_guidance), int(bool(use_ddpm_plus)), float(sharp_f),
                            float(bright_f), _p(out), _p(tx0), _p(txt))
         return (out, tx0, txt) if trace else out
+
+
+def set_num_threads(n: int) -> None:
+    lib().tld_o_set_num_threads(int(n))
 
 
 def num_threads() -> int:

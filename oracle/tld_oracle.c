@@ -540,6 +540,15 @@ TLD_O_EXPORT void tld_o_sample(const tld_o_model *m, const float *x_T, const flo
     free(xt); free(x2); free(o2); free(x0); free(x0_prev); free(lab2); free(sig); free(rs);
 }
 
+/* bench.py's cpu_baseline leg only: cap the OpenMP team (all hardware threads is the default; SMT siblings hurt here) */
+TLD_O_EXPORT void tld_o_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 TLD_O_EXPORT int tld_o_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -183,6 +183,7 @@ enum GemmEpilogue {
     EPI_QKV_LN = 5,      // EPI_QKV with LayerNorm-1 folded in (A = raw residual stream, see GemmParams::ln_stats)
     EPI_UP_DWCONV = 4,   // bf16(C + bias) -> depthwise 3x3 + bias + GELU over the tile's 16x16 image -> [M,N]
                          // (MLP up projection fused with the depthwise conv; needs ntok == 256, BN == 256)
+    EPI_UP_DWCONV2 = 6,  // the same fusion on a token-pair image with packed-bf16 taps (v_dot2c_f32_bf16), see tld_gemm.hip
 };
 
 struct GemmParams {
@@ -196,6 +197,8 @@ struct GemmParams {
     const float* bias;            // EPI_BIAS_*
     const float* dw_w9c;          // EPI_UP_DWCONV: HALVED depthwise weights [9][N]  (the epilogue's GELU takes x / 2)
     const float* dw_b;            // EPI_UP_DWCONV: HALVED depthwise bias [N]
+    const uint32_t* dw_wpk;       // EPI_UP_DWCONV2: HALVED depthwise taps as packed bf16 pairs [3 window rows][4 kinds][N]:
+                                  //   kinds (lo, hi): (0, w0), (w1, w2) for even output columns; (w0, w1), (w2, 0) for odd ones
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
     // LayerNorm-1 folded into the QKV GEMM (EPI_QKV_LN): the producers of the residual stream (embed, EPI_BIAS_RESID)
     // leave per-row partial sums (sum x, sum x^2) of the ROUNDED values, one slot per 96-column group (slot index =

@@ -70,6 +70,7 @@ struct Layer {
     float *qkv_c1 = nullptr, *qkv_b1 = nullptr;           // [3d] column sums of qkv_wf; beta1 . Wqkv^T
     float *up_b = nullptr, *dw_w9c = nullptr, *dw_b = nullptr, *down_b = nullptr;
     float *dw_w9c_half = nullptr, *dw_b_half = nullptr;   // 0.5 x (exact): operands of the fused up-projection epilogue
+    uint32_t* dw_wpk = nullptr;                           // the halved taps as packed bf16 pairs [3][4][hid] (EPI_UP_DWCONV2)
     bf16 *up_wf = nullptr;                                // bf16(gamma3 (.) Wup): LayerNorm-3 folded into the up-projection
     float *up_c1 = nullptr, *up_b1 = nullptr;             // [hid] column sums of up_wf; up_b + beta3 . Wup^T
     float *n1_w = nullptr, *n1_b = nullptr, *n2_w = nullptr, *n2_b = nullptr, *n3_w = nullptr, *n3_b = nullptr;
@@ -86,6 +87,7 @@ struct tld_engine {
     int d = 0, L = 0, H = 0, ntok = 0, grid = 0, pd = 0, hid = 0, img = 0, ne = 0, text = 0;
     bool finalized = false;
     bool fuse_dwconv = true;            // TLD_FUSE_DWCONV=0 selects the two-kernel path (A/B testing)
+    bool updw_v2 = true;                // TLD_UPDW_V2=0: first form of the fused depthwise epilogue (fp32 taps, A/B testing)
     std::map<std::string, HostTensor> host;
     std::vector<void*> allocs;
     int64_t weight_bytes = 0;
@@ -331,12 +333,13 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             GemmParams g{};
             g.A = e->xn; g.lda = d; g.W = Ly.up_w; g.ldw = d; g.M = M; g.N = e->hid; g.K = d;
             g.out_bf16 = e->hid2; g.ldo = e->hid; g.bias = Ly.up_b; g.dw_w9c = Ly.dw_w9c_half; g.dw_b = Ly.dw_b_half;
+            g.dw_wpk = Ly.dw_wpk;
 #ifdef TLD_RESID_BF16
             if (fold3) {    // LN3 inside the epilogue: raw residual rows x gamma-scaled weights, statistics from cross_row
                 g.A = e->x; g.W = Ly.up_wf; g.bias = Ly.up_b1; g.ln_c1 = Ly.up_c1; g.row_stats = e->row_stats;
             }
 #endif
-            launch_gemm(g, EPI_UP_DWCONV, s);
+            launch_gemm(g, e->updw_v2 ? EPI_UP_DWCONV2 : EPI_UP_DWCONV, s);
         } else {
             {   // hid1 = xn Wup^T + b
                 ProfScope ps(e, KC_GEMM_UP, s);
@@ -429,6 +432,7 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     e->layers.resize(e->L);
     if (const char* fd = getenv("TLD_FUSE_DWCONV")) e->fuse_dwconv = atoi(fd) != 0;
     if (const char* sl = getenv("TLD_SHARE_L0")) e->share_l0 = atoi(sl) != 0;
+    if (const char* v2 = getenv("TLD_UPDW_V2")) e->updw_v2 = atoi(v2) != 0;
     if (const char* fl = getenv("TLD_FOLD_LN3")) e->fold_ln3 = atoi(fl) != 0;
     if (const char* fl = getenv("TLD_FOLD_LN1")) e->fold_ln1 = atoi(fl) != 0;
 #ifndef TLD_RESID_BF16
@@ -581,6 +585,22 @@ int tld_engine_finalize_weights(tld_engine* e) {
             HIP_TRY(hipMemcpy(Ly.dw_w9c_half, tr.data(), tr.size() * sizeof(float), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(Ly.dw_b_half, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
             e->weight_bytes += (int64_t)(tr.size() + hb.size()) * 4;
+            // packed bf16 tap pairs for the v_dot2c form: per window row du and channel c, with (w0, w1, w2) the halved
+            // taps of that row:  kind 0 = (lo 0, hi w0), 1 = (w1, w2), 2 = (w0, w1), 3 = (w2, 0)
+            std::vector<uint32_t> pk((size_t)(12 * hid));
+            for (int du = 0; du < 3; ++du)
+                for (int64_t c = 0; c < hid; ++c) {
+                    const uint32_t w0 = f32_to_bf16_rne(tr[(size_t)((du * 3 + 0) * hid + c)]);
+                    const uint32_t w1 = f32_to_bf16_rne(tr[(size_t)((du * 3 + 1) * hid + c)]);
+                    const uint32_t w2 = f32_to_bf16_rne(tr[(size_t)((du * 3 + 2) * hid + c)]);
+                    pk[(size_t)((du * 4 + 0) * hid + c)] = w0 << 16;
+                    pk[(size_t)((du * 4 + 1) * hid + c)] = w1 | (w2 << 16);
+                    pk[(size_t)((du * 4 + 2) * hid + c)] = w0 | (w1 << 16);
+                    pk[(size_t)((du * 4 + 3) * hid + c)] = w2;
+                }
+            if (int rc = dev_alloc(e, &Ly.dw_wpk, pk.size())) return rc;
+            HIP_TRY(hipMemcpy(Ly.dw_wpk, pk.data(), pk.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            e->weight_bytes += (int64_t)pk.size() * 4;
         }
 #undef LK
     }
@@ -769,13 +789,15 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     g.dbg_no_dma = (getenv("TLD_GEMM_DBG") && atoi(getenv("TLD_GEMM_DBG")) == 2) ? 1 : 0;
     g.dbg_epi = getenv("TLD_EPI_DBG") ? atoi(getenv("TLD_EPI_DBG")) : 0;
     float *dww = nullptr;
-    if (epilogue == EPI_UP_DWCONV) {
+    if (epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2) {
         if (M % 256 || N % 256) return fail(TLD_ERR_INVALID, "fused depthwise epilogue needs M, N multiples of 256");
-        HIP_TRY(hipMalloc(&dww, (size_t)N * 10 * 4));
-        std::vector<float> hw((size_t)N * 10);
-        for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0.05f + 0.01f * (float)(i % 7);
+        HIP_TRY(hipMalloc(&dww, (size_t)N * 22 * 4));
+        std::vector<float> hw((size_t)N * 22);
+        for (size_t i = 0; i < (size_t)N * 10; ++i) hw[i] = 0.05f + 0.01f * (float)(i % 7);
+        uint32_t* pk = reinterpret_cast<uint32_t*>(hw.data() + (size_t)N * 10);
+        for (size_t i = 0; i < (size_t)N * 12; ++i) pk[i] = 0x3d803d00u + (uint32_t)(i % 5) * 0x00010001u;     // small bf16 pairs
         HIP_TRY(hipMemcpy(dww, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
-        g.dw_w9c = dww; g.dw_b = dww + (size_t)N * 9;
+        g.dw_w9c = dww; g.dw_b = dww + (size_t)N * 9; g.dw_wpk = reinterpret_cast<const uint32_t*>(dww + (size_t)N * 10);
     }
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));

@@ -18,6 +18,10 @@
 #define TLD_EPI_BIT(b) false
 #endif
 
+#ifndef TLD_KLOOP_STAGGER
+#define TLD_KLOOP_STAGGER 0   // 1: staggered 8-interval K-step (see gemm256p_kernel); A/B builds via -DTLD_KLOOP_STAGGER=1
+#endif
+
 #ifndef TLD_GLDS_AUX
 #define TLD_GLDS_AUX 0      // cache-policy bits of the tile DMA (experiment knob: 2 = nt; measured slower)
 #endif
@@ -84,6 +88,13 @@ struct G256P : G256<BN> {
     static constexpr int IMG_BYTES = 256 * IMG_PITCH;
     static constexpr int ROWSTAT_OFF = IMG_BYTES;    // folded LayerNorm-3: the tile's 256 (mean, rstd) pairs, behind the image
     static constexpr int UPDW_LDS = IMG_BYTES + 256 * 8;
+    // second form of the fused depthwise epilogue (EPI_UP_DWCONV2): image of TOKEN PAIRS, one dword = (token 2p, token 2p+1)
+    // of one channel, [128 pairs][256 channels] with a 1-KiB pitch (no padding needed: every access of a wave is a
+    // contiguous run), an all-zero pair-row for the rows above / below the image, then the (mean, rstd) pairs
+    static constexpr int IMG2_PITCH = 1024, IMG2_BYTES = 128 * IMG2_PITCH;
+    static constexpr int ZROW_OFF = IMG2_BYTES, ZROW_BYTES = 8 * IMG2_PITCH;
+    static constexpr int ROWSTAT2_OFF = ZROW_OFF + ZROW_BYTES;
+    static constexpr int UPDW2_LDS = ROWSTAT2_OFF + 256 * 8;
     static constexpr int SCRATCH = 4608;             // per-wave epilogue scratch (8 x 4608 <= one stage)
 };
 
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         // everywhere except the fp32 debug epilogue.  The V^T tiles of the QKV GEMM are swapped too and transposed on
         // their way through the epilogue scratch with 2-byte LDS writes: one K-loop instantiation instead of two took
         // the kernel from 245 to 213 VGPRs and 111 -> 110 us.
-        constexpr bool swapped = EPI != EPI_F32;
+        constexpr bool swapped = EPI != EPI_F32 && EPI != EPI_UP_DWCONV2;   // (the pair image wants lane = channel)
         bool v_tile = false;
         if constexpr (IS_QKV) v_tile = n0 >= 2 * p.d;
 
@@ -239,6 +250,79 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 if (p.trace && blockIdx.x == 0 && it == 0 && k < 16 && lane == 0)
                     p.trace[(wid * 16 + k) * 6 + slot] = __builtin_amdgcn_s_memtime();
             };
+#if TLD_KLOOP_STAGGER
+            // Staggered form (the 8-phase idea of the gfx950 GEMM template): the two waves of every SIMD are w and w + 4;
+            // waves 4-7 run ONE barrier interval behind waves 0-3, so in every interval one wave of each SIMD executes
+            // its 8 (12) MFMAs of a k-slice from registers at raised priority while its partner reads the next slice's
+            // fragments from LDS and issues the tile DMA -- the matrix pipe never waits for an LDS read and the two
+            // waves never compete for it.  8 barriers per K-step (R: reads + DMA | M: MFMAs), one fragment set.
+            //   hazards: fragments are waited for (lgkmcnt 0) BEFORE the barrier closing an R interval, so a stage is
+            //   free for DMA as soon as that barrier is passed; every wave waits for its own DMA pieces (vmcnt 0) before
+            //   the last barrier of a K-step, which both groups pass before anyone reads the next stage.
+            const int grp = wid >> 2;
+            wait_vmcnt<0>();                       // first K-step of the tile landed (own pieces) ...
+            __builtin_amdgcn_s_barrier();          // ... everybody's; also: the previous epilogue's scratch reads are done
+            if (grp) __builtin_amdgcn_s_barrier(); // stagger in
+            for (int k = 0; k < nk; ++k, ++g) {
+                if constexpr (LN) {
+                    if (k == 1) {
+                        static_assert(kLnSlots == 8, "one partial-sum row is 64 B");
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2) {
+                            const int piece = wid * 2 + q2;
+                            int row = m0 + piece * 16 + (lane >> 2);
+                            row = row < p.M ? row : p.M - 1;
+                            const char* src = reinterpret_cast<const char*>(p.ln_stats) + (size_t)row * 64 + (lane & 3) * 16;
+                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_RAW + piece * 1024), 16, 0, 0);
+                        }
+                        if (wid < 2) {
+                            int col = n0 + lane * 4;
+                            col = col < p.N ? col : 0;
+                            const float* src = (wid == 0 ? p.ln_c1 : p.ln_b1) + col;
+                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_CB + wid * 1024), 16, 0, 0);
+                        }
+                    }
+                }
+                if constexpr (EPI == EPI_UP_DWCONV || EPI == EPI_UP_DWCONV2) {
+                    constexpr int RS_OFF = EPI == EPI_UP_DWCONV ? G::ROWSTAT_OFF : G::ROWSTAT2_OFF;
+                    if (k == 1 && p.row_stats && wid < 2) {
+                        const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + RS_OFF + wid * 1024), 16, 0, 0);
+                    }
+                }
+                const char* st = smem + (g & 1) * G::STAGE_BYTES;
+                char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
+                const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV && EPI != EPI_UP_DWCONV2);
+                const int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
+                if (k + 1 == nk && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    // ---- R interval
+                    load_frags(st, ks, a0, b0);
+                    if (ks < 2 && more && !p.dbg_no_dma) {
+#pragma unroll
+                        for (int q2 = 0; q2 < NP; ++q2) {
+                            if (q2 < ks * ((NP + 1) / 2) || q2 >= (ks + 1) * ((NP + 1) / 2)) continue;
+                            dma_piece(q2, pkb, nst);
+                        }
+                    }
+                    if (ks == 3) wait_vmcnt<0>();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- M interval
+                    __builtin_amdgcn_s_setprio(1);
+                    mma(a0, b0);
+                    __builtin_amdgcn_s_setprio(0);
+                    if (ks == 3) wait_vmcnt<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (!grp) __builtin_amdgcn_s_barrier();        // stagger out: both groups are past their last MFMA
+#else
             for (int k = 0; k < nk; ++k, ++g) {
                 stamp(k, 0);
                 wait_vmcnt<0>();                   // own DMA pieces of step g landed (and earlier epilogue stores)
@@ -266,17 +350,18 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         }
                     }
                 }
-                if constexpr (EPI == EPI_UP_DWCONV) {
+                if constexpr (EPI == EPI_UP_DWCONV || EPI == EPI_UP_DWCONV2) {
                     // folded LayerNorm-3: the tile's 256 (mean, rstd) pairs travel by DMA into LDS behind the image while
                     // the K loop runs (K-step 1: every wave is past the previous tile's epilogue, which read them)
+                    constexpr int RS_OFF = EPI == EPI_UP_DWCONV ? G::ROWSTAT_OFF : G::ROWSTAT2_OFF;
                     if (k == 1 && p.row_stats && wid < 2) {
                         const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
-                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::ROWSTAT_OFF + wid * 1024), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + RS_OFF + wid * 1024), 16, 0, 0);
                     }
                 }
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
-                const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV);
+                const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV && EPI != EPI_UP_DWCONV2);
                 const int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
                 if (k + 1 == nk && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
                 auto pieces = [&](int lo, int hi_) {
@@ -316,6 +401,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 stamp(k, 5);
             }
             if constexpr (BN != 384) mma(a1, b1);  // k-slice 3 of the tile's last step
+#endif
         };
         if constexpr (swapped) kloop(std::true_type{}); else kloop(std::false_type{});
 
@@ -475,6 +561,130 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         col(jj + 3, c1v); emit(c2v, c0v, c1v, jj + 2);
                     }
                     col_zero(c2v); emit(c0v, c1v, c2v, jj);          // jj == 15
+                }
+                // the ring restarts for the next tile: its first K-step could not be prefetched (LDS was the image)
+                __builtin_amdgcn_s_barrier();
+                if (has_next) issue(m0n, n0n, g);
+            } else if constexpr (EPI == EPI_UP_DWCONV2) {
+                // Second form of the fused depthwise 3x3 + GELU epilogue.  The K loop runs in the NATURAL MFMA order, so a
+                // lane owns a channel and four consecutive tokens (= four consecutive image columns of one image row)
+                // per register quad: two v_cvt_pk_bf16_f32 give the dwords (col 2q, col 2q+1) of that channel, and the
+                // image in LDS is [token pair][channel] dwords.  The conv then needs no unpacking at all: every tap
+                // pair is one v_dot2c_f32_bf16 (fp32 accumulate) against a packed bf16 weight pair,
+                //   out(col 2q)   = (0,w0).P[q-1] + (w1,w2).P[q]          out(col 2q+1) = (w0,w1).P[q] + (w2,0).P[q+1]
+                // per image row of the 3x3 window: 6 instructions per output instead of 9 FMAs + 3 unpacks.  The depthwise
+                // weights are rounded to bf16 for this (like every other weight on the MFMA path); bias, accumulation and
+                // GELU stay fp32.  A thread owns a channel quad and TWO ADJACENT image rows (4 window rows in registers,
+                // 16 independent accumulation chains per step); rows outside the image are read from an all-zero
+                // pair-row in LDS, columns outside the image are zero registers: no border code in the loop.
+                static_assert(BN == 256, "fused depthwise epilogue is written for 256-column tiles");
+                char* H = smem;
+                {   // zero pair-row (never overwritten by the stages: it lies behind them)
+                    if (it == 0) *reinterpret_cast<u32x4*>(smem + G::ZROW_OFF + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};
+                }
+                const bool ln3 = p.row_stats != nullptr;
+                float cst[G::TN], bst[G::TN];
+#pragma unroll
+                for (int j = 0; j < G::TN; ++j) {
+                    const int c = n0 + wn * 64 + j * 32 + l31;
+                    bst[j] = p.bias[c];
+                    cst[j] = ln3 ? p.ln_c1[c] : 0.f;
+                }
+                if (!TLD_EPI_BIT(8))
+#pragma unroll
+                for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int tok0 = wm * G::WROWS + i * 32 + 8 * rq + 4 * hi;          // 4 consecutive tokens
+                        float rs[4] = {1.f, 1.f, 1.f, 1.f}, nm[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (ln3) {
+                            const float4 s01 = *reinterpret_cast<const float4*>(smem + G::ROWSTAT2_OFF + tok0 * 8);
+                            const float4 s23 = *reinterpret_cast<const float4*>(smem + G::ROWSTAT2_OFF + tok0 * 8 + 16);
+                            rs[0] = s01.y; nm[0] = -s01.y * s01.x; rs[1] = s01.w; nm[1] = -s01.w * s01.z;
+                            rs[2] = s23.y; nm[2] = -s23.y * s23.x; rs[3] = s23.w; nm[3] = -s23.w * s23.z;
+                        }
+#pragma unroll
+                        for (int j = 0; j < G::TN; ++j) {
+                            bf16x2 lo, hi2;
+                            lo[0] = (bf16)fmaf(rs[0], acc[i][j][rq * 4 + 0], fmaf(nm[0], cst[j], bst[j]));
+                            lo[1] = (bf16)fmaf(rs[1], acc[i][j][rq * 4 + 1], fmaf(nm[1], cst[j], bst[j]));
+                            hi2[0] = (bf16)fmaf(rs[2], acc[i][j][rq * 4 + 2], fmaf(nm[2], cst[j], bst[j]));
+                            hi2[1] = (bf16)fmaf(rs[3], acc[i][j][rq * 4 + 3], fmaf(nm[3], cst[j], bst[j]));
+                            char* dst = H + (tok0 >> 1) * G::IMG2_PITCH + (wn * 64 + j * 32 + l31) * 4;
+                            *reinterpret_cast<bf16x2*>(dst) = lo;
+                            *reinterpret_cast<bf16x2*>(dst + G::IMG2_PITCH) = hi2;
+                        }
+                    }
+                __builtin_amdgcn_s_barrier();
+                if (!TLD_EPI_BIT(4)) {
+                    const int cq = threadIdx.x & 63;                     // channel quad
+                    const int c0 = n0 + cq * 4;
+                    u32x4 WA[3], WB[3], WC[3], WD[3];                    // packed bf16 weight pairs, 4 channels each
+#pragma unroll
+                    for (int du = 0; du < 3; ++du) {
+                        WA[du] = *reinterpret_cast<const u32x4*>(p.dw_wpk + (size_t)(du * 4 + 0) * p.N + c0);
+                        WB[du] = *reinterpret_cast<const u32x4*>(p.dw_wpk + (size_t)(du * 4 + 1) * p.N + c0);
+                        WC[du] = *reinterpret_cast<const u32x4*>(p.dw_wpk + (size_t)(du * 4 + 2) * p.N + c0);
+                        WD[du] = *reinterpret_cast<const u32x4*>(p.dw_wpk + (size_t)(du * 4 + 3) * p.N + c0);
+                    }
+                    const float4 bsv = *reinterpret_cast<const float4*>(p.dw_b + c0);
+                    const f32x4 bs = {bsv.x, bsv.y, bsv.z, bsv.w};
+                    const int w2 = threadIdx.x >> 6;                     // output image rows 2 w2 and 2 w2 + 1
+                    const char* rb[4];                                   // window rows 2 w2 - 1 .. 2 w2 + 2 (8 pair-columns each)
+                    rb[0] = (w2 == 0 ? smem + G::ZROW_OFF : H + (2 * w2 - 1) * 8 * G::IMG2_PITCH) + cq * 16;
+                    rb[1] = H + (2 * w2) * 8 * G::IMG2_PITCH + cq * 16;
+                    rb[2] = H + (2 * w2 + 1) * 8 * G::IMG2_PITCH + cq * 16;
+                    rb[3] = (w2 == 7 ? smem + G::ZROW_OFF : H + (2 * w2 + 2) * 8 * G::IMG2_PITCH) + cq * 16;
+                    auto ld = [&](int q, u32x4 (&c)[4]) {
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) c[k4] = *reinterpret_cast<const u32x4*>(rb[k4] + q * G::IMG2_PITCH);
+                    };
+                    auto zero = [&](u32x4 (&c)[4]) {
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; ++k4) c[k4] = u32x4{0u, 0u, 0u, 0u};
+                    };
+                    auto dot2 = [](unsigned a, unsigned b, float c) {
+                        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+                    };
+                    bf16* dst0 = p.out_bf16 + ((size_t)m0 + (size_t)w2 * 32) * p.ldo + c0;
+                    auto emit = [&](const u32x4 (&L)[4], const u32x4 (&Mc)[4], const u32x4 (&R)[4], int q) {
+#pragma unroll
+                        for (int rr = 0; rr < 2; ++rr) {
+                            f32x4 ae = bs, ao = bs;
+#pragma unroll
+                            for (int du = 0; du < 3; ++du)
+#pragma unroll
+                                for (int ch = 0; ch < 4; ++ch) {
+                                    ae[ch] = dot2(L[rr + du][ch], WA[du][ch], ae[ch]);
+                                    ao[ch] = dot2(Mc[rr + du][ch], WC[du][ch], ao[ch]);
+                                    ae[ch] = dot2(Mc[rr + du][ch], WB[du][ch], ae[ch]);
+                                    ao[ch] = dot2(R[rr + du][ch], WD[du][ch], ao[ch]);
+                                }
+                            f32x2 e0 = {ae[0], ae[1]}, e1 = {ae[2], ae[3]}, o0 = {ao[0], ao[1]}, o1 = {ao[2], ao[3]};
+                            if (!TLD_EPI_BIT(2)) {
+                                e0 = gelu_erf_fast2_half(e0); e1 = gelu_erf_fast2_half(e1);
+                                o0 = gelu_erf_fast2_half(o0); o1 = gelu_erf_fast2_half(o1);
+                            }
+                            bf16x4 oe, oo;
+                            oe[0] = (bf16)e0[0]; oe[1] = (bf16)e0[1]; oe[2] = (bf16)e1[0]; oe[3] = (bf16)e1[1];
+                            oo[0] = (bf16)o0[0]; oo[1] = (bf16)o0[1]; oo[2] = (bf16)o1[0]; oo[3] = (bf16)o1[1];
+                            if (!TLD_EPI_BIT(1)) {
+                                TLD_STORE(reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 16 + 2 * q) * p.ldo), oe);
+                                TLD_STORE(reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 16 + 2 * q + 1) * p.ldo), oo);
+                            }
+                        }
+                    };
+                    u32x4 c0v[4], c1v[4], c2v[4];
+                    zero(c0v);
+                    ld(0, c1v);
+#pragma unroll 1
+                    for (int q = 0; q < 6; q += 3) {
+                        ld(q + 1, c2v); emit(c0v, c1v, c2v, q);
+                        ld(q + 2, c0v); emit(c1v, c2v, c0v, q + 1);
+                        ld(q + 3, c1v); emit(c2v, c0v, c1v, q + 2);
+                    }
+                    ld(7, c2v); emit(c0v, c1v, c2v, 6);
+                    zero(c0v); emit(c1v, c2v, c0v, 7);
                 }
                 // the ring restarts for the next tile: its first K-step could not be prefetched (LDS was the image)
                 __builtin_amdgcn_s_barrier();
@@ -674,12 +884,13 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     // four groups for the up-projection (neutral), two / four groups for the down-projection (A is the 201 MB
     // operand there: neutral / 175 -> 195 us).  Large launches only: every XCD cell needs workgroups of its own.
     GemmParams pg = p;
-    if ((epilogue == EPI_UP_DWCONV || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
+    if ((epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
         pg.xcd_ngroups = 2;
 #define TLD_L256P(E)                                                                                  \
     do {                                                                                              \
         constexpr int lds = (E) == EPI_UP_DWCONV && G::UPDW_LDS > G::LDS_BYTES ? G::UPDW_LDS                     \
-                            : ((E) == EPI_QKV_LN ? G::QKVLN_LDS : G::LDS_BYTES);                      \
+                            : ((E) == EPI_UP_DWCONV2 ? G::UPDW2_LDS                                   \
+                            : ((E) == EPI_QKV_LN ? G::QKVLN_LDS : G::LDS_BYTES));                     \
         static bool once = false;                                                                     \
         if (!once) {                                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E>),                \
@@ -698,6 +909,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
             case EPI_BIAS_BF16: TLD_L256P(EPI_BIAS_BF16); break;
             case EPI_BIAS_RESID: TLD_L256P(EPI_BIAS_RESID); break;
             case EPI_UP_DWCONV: if constexpr (BN == 256) { TLD_L256P(EPI_UP_DWCONV); } break;
+            case EPI_UP_DWCONV2: if constexpr (BN == 256) { TLD_L256P(EPI_UP_DWCONV2); } break;
             default: break;
         }
     }
@@ -723,7 +935,7 @@ int choose_bn(long M, long N, int epilogue) {
     if (epilogue == EPI_BIAS_RESID && N % 192 == 0) bn = 192;
     if (wide && epilogue == EPI_BIAS_RESID && N % 384 == 0 && (ntm * (N / 384)) % 256 == 0) bn = 384;
     if (force) bn = atoi(force);
-    if (epilogue == EPI_UP_DWCONV) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
+    if (epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
     if (bn == 192 && (epilogue != EPI_BIAS_RESID || N % 192)) bn = 128;
     if (bn == 384 && (epilogue != EPI_BIAS_RESID || N % 384)) bn = 128;
     if (bn != 256 && bn != 192 && bn != 384) bn = 128;
