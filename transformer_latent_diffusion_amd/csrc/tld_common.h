@@ -110,9 +110,9 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2_half(f32x2 y) {
     p = __builtin_elementwise_fma(p, ay, f32x2{0.09973469393f, 0.09973469393f});
     p = __builtin_elementwise_fma(p, ay, f32x2{1.0f, 1.0f});
     f32x2 r = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
-    r *= r; r *= r; r *= r; r *= r;
-    const f32x2 e = {copysignf(1.0f - r[0], y[0]), copysignf(1.0f - r[1], y[1])};       // erf(x / sqrt2)
-    return __builtin_elementwise_fma(y, e, y);
+    r *= r; r *= r; r *= r; r *= r;                                                      // erfc(sqrt2 |y|)
+    // y (1 + erf(sqrt2 y)) = (y + |y|) - |y| erfc(sqrt2 |y|)  for either sign of y: no copysign / select needed
+    return __builtin_elementwise_fma(-ay, r, y + ay);
 }
 // (A transcendental-free degree-9 polynomial erf was measured ~4 % SLOWER end to end: its 10-deep dependent FMA
 // chain is latency-bound at the 2 waves/SIMD of the fused GEMM epilogue.)
@@ -230,8 +230,9 @@ void launch_attention(const bf16* qk, const bf16* vt, bf16* att, int batch, int 
                       hipStream_t s);
 
 // depthwise 3x3 (zero pad) + bias + exact GELU on channels-last [B, g, g, C] bf16
-void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c /*[9][C]*/, const float* bias,
-                        int batch, int grid, int channels, hipStream_t s);
+// (w9c_half / bias_half: the same tables times 0.5, used by the spatially tiled kernel's half-argument GELU)
+void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c /*[9][C]*/, const float* bias, const float* w9c_half,
+                        const float* bias_half, int batch, int grid, int channels, hipStream_t s);
 
 struct EmbedParams {
     const float* x;               // [B,C,S,S] fp32

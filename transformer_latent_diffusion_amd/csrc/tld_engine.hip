@@ -311,7 +311,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
         // 256 px (16x16 tokens): one GEMM tile row-block is one image, so the depthwise conv + GELU run inside the
         // up-projection's epilogue and the pre-conv hidden never reaches HBM.  Other grids: separate kernels.
         const bool fuse_dw = e->fuse_dwconv && e->grid == 16 && e->hid % 256 == 0;
-        const bool fold3 = fuse_dw && e->fold_ln3;      // LN3 applied in that epilogue: cross_row writes row statistics, not xn
+        const bool fold3 = e->fold_ln3;                 // LN3 applied in the up-projection's epilogue: cross_row writes row statistics, not xn
         {   // x += att; x += CA(LN2 x, y); xn = LN3(x)
             ProfScope ps(e, KC_CROSS, s);
             CrossRowParams cp{};
@@ -346,11 +346,16 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
                 GemmParams g{};
                 g.A = e->xn; g.lda = d; g.W = Ly.up_w; g.ldw = d; g.M = M; g.N = e->hid; g.K = d;
                 g.out_bf16 = e->hid1; g.ldo = e->hid; g.bias = Ly.up_b;
+#ifdef TLD_RESID_BF16
+                if (fold3) {
+                    g.A = e->x; g.W = Ly.up_wf; g.bias = Ly.up_b1; g.ln_c1 = Ly.up_c1; g.row_stats = e->row_stats;
+                }
+#endif
                 launch_gemm(g, EPI_BIAS_BF16, s);
             }
             {
                 ProfScope ps(e, KC_DWCONV, s);
-                launch_dwconv_gelu(e->hid1, e->hid2, Ly.dw_w9c, Ly.dw_b, batch, e->grid, e->hid, s);
+                launch_dwconv_gelu(e->hid1, e->hid2, Ly.dw_w9c, Ly.dw_b, Ly.dw_w9c_half, Ly.dw_b_half, batch, e->grid, e->hid, s);
             }
         }
         {   // x += hid2 Wdown^T + b
@@ -442,8 +447,9 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     // LayerNorm-1 fold: needs the down projection's 96-column partial sums (d % 192 == 0, at most 8 groups) and a QKV
     // width the 256-wide kernel takes for every batch size
     e->fold_ln1 = e->fold_ln1 && gemm_resid_stat_slots(e->d) > 0 && (3 * e->d) % 256 == 0;
-    // only where the fused up-projection and the statistics-writing row kernel exist
-    e->fold_ln3 = e->fold_ln3 && e->fuse_dwconv && grid == 16 && e->hid % 256 == 0 && cross_row_supports_ln3_stats(e->d);
+    // needs the statistics-writing row kernel; both up-projection epilogues (fused depthwise at 16 x 16 tokens, plain
+    // bias + bf16 otherwise) apply the fold
+    e->fold_ln3 = e->fold_ln3 && e->hid % 256 == 0 && cross_row_supports_ln3_stats(e->d);
     *out = e;
     return TLD_OK;
 }
@@ -802,9 +808,10 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
     unsigned long long* trace = nullptr;
+    constexpr size_t kTraceWords = 8 * 16 * 16;
     if (getenv("TLD_GEMM_TRACE")) {
-        HIP_TRY(hipMalloc(&trace, 8 * 16 * 6 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(trace, 0, 8 * 16 * 6 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&trace, kTraceWords * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(trace, 0, kTraceWords * sizeof(unsigned long long)));
         g.trace = trace;
     }
     auto run = [&]() { launch_gemm(g, epilogue, nullptr); };
@@ -817,16 +824,29 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     HIP_TRY(hipEventElapsedTime(&ms, a, b));
     *avg_ms = ms / iters;
     if (trace) {
-        std::vector<unsigned long long> h(8 * 16 * 6);
+        std::vector<unsigned long long> h(kTraceWords);
         HIP_TRY(hipMemcpy(h.data(), trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        const unsigned long long t00 = h[0];
-        printf("# s_memtime trace, workgroup 0, first tile: per wave, per K-step: top | +vmcnt | +barrier | +grp0 | +grp3 issued | +lgkm  (cycles since wave0 step0)\n");
-        for (int w = 0; w < 8; ++w)
-            for (int k = 0; k < 12; ++k) {
-                printf("w%d k%2d:", w, k);
-                for (int sl = 0; sl < 6; ++sl) printf(" %7lld", (long long)(h[(w * 16 + k) * 6 + sl] - t00));
-                printf("\n");
-            }
+        const bool stag = h[3] != 0 && h[8] != 0;          // the staggered K loop writes 16 stamps per K-step, the plain one 6
+        unsigned long long t00 = ~0ull;
+        for (size_t i = 0; i < h.size(); ++i) if (h[i] && h[i] < t00) t00 = h[i];
+        if (stag) {
+            printf("# s_memtime trace (staggered K loop), workgroup 0, first tile; per wave and K-step, for each k-slice: R start | frags in "
+                   "registers | past barrier 1 | MFMAs issued  (cycles since the first stamp)\n");
+            for (int w = 0; w < 8; ++w)
+                for (int k = 0; k < 12; ++k) {
+                    printf("w%d k%2d:", w, k);
+                    for (int sl = 0; sl < 16; ++sl) printf(" %6lld%s", (long long)(h[(w * 16 + k) * 16 + sl] - t00), (sl & 3) == 3 ? " |" : "");
+                    printf("\n");
+                }
+        } else {
+            printf("# s_memtime trace, workgroup 0, first tile: per wave, per K-step: top | +vmcnt | +barrier | +grp0 | +grp3 issued | +lgkm  (cycles since the first stamp)\n");
+            for (int w = 0; w < 8; ++w)
+                for (int k = 0; k < 12; ++k) {
+                    printf("w%d k%2d:", w, k);
+                    for (int sl = 0; sl < 6; ++sl) printf(" %7lld", (long long)(h[(w * 16 + k) * 6 + sl] - t00));
+                    printf("\n");
+                }
+        }
         hipFree(trace);
     }
     hipEventDestroy(a); hipEventDestroy(b);

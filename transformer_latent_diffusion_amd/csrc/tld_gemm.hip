@@ -19,7 +19,11 @@
 #endif
 
 #ifndef TLD_KLOOP_STAGGER
-#define TLD_KLOOP_STAGGER 0   // 1: staggered 8-interval K-step (see gemm256p_kernel); A/B builds via -DTLD_KLOOP_STAGGER=1
+#define TLD_KLOOP_STAGGER 1   // staggered 8-interval K-step (see gemm256p_kernel); -DTLD_KLOOP_STAGGER=0 builds the one-barrier form (A/B)
+#endif
+
+#ifndef TLD_KLOOP_NS
+#define TLD_KLOOP_NS 1        // k-slices per barrier interval of the staggered K loop (1 or 2); the 384-wide tile always uses 1
 #endif
 
 #ifndef TLD_GLDS_AUX
@@ -94,7 +98,10 @@ struct G256P : G256<BN> {
     static constexpr int IMG2_PITCH = 1024, IMG2_BYTES = 128 * IMG2_PITCH;
     static constexpr int ZROW_OFF = IMG2_BYTES, ZROW_BYTES = 8 * IMG2_PITCH;
     static constexpr int ROWSTAT2_OFF = ZROW_OFF + ZROW_BYTES;
-    static constexpr int UPDW2_LDS = ROWSTAT2_OFF + 256 * 8;
+    static constexpr int CB2_OFF = ROWSTAT2_OFF + 256 * 8;          // c1 | bias of the tile's 256 columns (fp32)
+    static constexpr int UPDW2_LDS = CB2_OFF + 2048;
+    static constexpr int PLAINRS_OFF = LDS_BYTES;    // EPI_BIAS_BF16 with folded LayerNorm-3: the tile's 256 (mean, rstd) pairs
+    static constexpr int PLAINLN_LDS = LDS_BYTES + 256 * 8;
     static constexpr int SCRATCH = 4608;             // per-wave epilogue scratch (8 x 4608 <= one stage)
 };
 
@@ -247,15 +254,18 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             constexpr int NP = G::A_PIECES + G::B_PIECES;           // pieces per wave per K-step
             // optional cycle trace (block 0, first 16 K-steps of its first tile): 6 stamps per step per wave
             auto stamp = [&](int k, int slot) {
+#ifdef TLD_GEMM_TRACE_BUILD
                 if (p.trace && blockIdx.x == 0 && it == 0 && k < 16 && lane == 0)
                     p.trace[(wid * 16 + k) * 6 + slot] = __builtin_amdgcn_s_memtime();
+#endif
             };
 #if TLD_KLOOP_STAGGER
+            {
             // Staggered form (the 8-phase idea of the gfx950 GEMM template): the two waves of every SIMD are w and w + 4;
             // waves 4-7 run ONE barrier interval behind waves 0-3, so in every interval one wave of each SIMD executes
             // its 8 (12) MFMAs of a k-slice from registers at raised priority while its partner reads the next slice's
             // fragments from LDS and issues the tile DMA -- the matrix pipe never waits for an LDS read and the two
-            // waves never compete for it.  8 barriers per K-step (R: reads + DMA | M: MFMAs), one fragment set.
+            // waves never compete for it.  Intervals alternate R (fragment reads + tile DMA) and M (MFMAs).
             //   hazards: fragments are waited for (lgkmcnt 0) BEFORE the barrier closing an R interval, so a stage is
             //   free for DMA as soon as that barrier is passed; every wave waits for its own DMA pieces (vmcnt 0) before
             //   the last barrier of a K-step, which both groups pass before anyone reads the next stage.
@@ -283,11 +293,25 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         }
                     }
                 }
+                if constexpr (EPI == EPI_BIAS_BF16) {      // folded LayerNorm-3 of the plain up-projection (grids other than 16 x 16)
+                    if (k == 1 && p.row_stats && wid < 2) {
+                        int r0s = m0 + wid * 128 + lane * 2;                     // 2 rows (16 B) per lane, clamped at the matrix end
+                        r0s = r0s + 1 < p.M ? r0s : (p.M >= 2 ? p.M - 2 : 0);
+                        const char* src = reinterpret_cast<const char*>(p.row_stats + r0s);
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::PLAINRS_OFF + wid * 1024), 16, 0, 0);
+                    }
+                }
                 if constexpr (EPI == EPI_UP_DWCONV || EPI == EPI_UP_DWCONV2) {
                     constexpr int RS_OFF = EPI == EPI_UP_DWCONV ? G::ROWSTAT_OFF : G::ROWSTAT2_OFF;
                     if (k == 1 && p.row_stats && wid < 2) {
                         const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
                         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + RS_OFF + wid * 1024), 16, 0, 0);
+                    }
+                    if constexpr (EPI == EPI_UP_DWCONV2) {      // waves 2 / 3: c1 / bias of the tile's columns
+                        if (k == 1 && (wid == 3 || (wid == 2 && p.row_stats))) {
+                            const float* src = (wid == 2 ? p.ln_c1 : p.bias) + n0 + lane * 4;
+                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::CB2_OFF + (wid - 2) * 1024), 16, 0, 0);
+                        }
                     }
                 }
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
@@ -295,33 +319,53 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV && EPI != EPI_UP_DWCONV2);
                 const int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
                 if (k + 1 == nk && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
+                // NS k-slices per interval: 1 -> 8 intervals (barriers) per K-step with 8 (12) MFMAs each; 2 -> 4 intervals with
+                // 16 MFMAs each and two fragment sets (the 384-wide tile has no registers for a second set)
+                constexpr int NS = (BN == 384) ? 1 : TLD_KLOOP_NS;
+                constexpr int NI = 4 / NS;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    // ---- R interval
-                    load_frags(st, ks, a0, b0);
-                    if (ks < 2 && more && !p.dbg_no_dma) {
+                for (int h = 0; h < NI; ++h) {
+                    // ---- R interval   (optional s_memtime trace: 4 stamps per interval pair, see tld_debug_gemm_bench)
+                    auto stamp4 = [&](int slot) {
+#ifdef TLD_GEMM_TRACE_BUILD     // (-DTLD_GEMM_TRACE_BUILD only: even a not-taken stamp is an exec-mask branch per interval)
+                        if (p.trace && blockIdx.x == 0 && it == 0 && k < 16 && lane == 0)
+                            p.trace[(wid * 16 + k) * 16 + h * NS * 4 + slot] = __builtin_amdgcn_s_memtime();
+#endif
+                    };
+                    stamp4(0);
+                    load_frags(st, h * NS, a0, b0);
+                    if constexpr (NS == 2) load_frags(st, h * NS + 1, a1, b1);
+                    // tile DMA of the next K-step: early in the step, so that every piece has >= 2 intervals to land before
+                    // the vmcnt(0) of the step's last interval (NS == 2: all in the first R interval; NS == 1: first two)
+                    if (h < 2 / NS && more && !p.dbg_no_dma) {
+                        constexpr int PER = NS == 2 ? NP : (NP + 1) / 2;
 #pragma unroll
                         for (int q2 = 0; q2 < NP; ++q2) {
-                            if (q2 < ks * ((NP + 1) / 2) || q2 >= (ks + 1) * ((NP + 1) / 2)) continue;
+                            if (q2 < h * PER || q2 >= (h + 1) * PER) continue;
                             dma_piece(q2, pkb, nst);
                         }
                     }
-                    if (ks == 3) wait_vmcnt<0>();
+                    if (h == NI - 1) wait_vmcnt<0>();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    stamp4(1);
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
+                    stamp4(2);
                     // ---- M interval
                     __builtin_amdgcn_s_setprio(1);
                     mma(a0, b0);
+                    if constexpr (NS == 2) mma(a1, b1);
                     __builtin_amdgcn_s_setprio(0);
-                    if (ks == 3) wait_vmcnt<0>();
+                    if (h == NI - 1) wait_vmcnt<0>();
+                    stamp4(3);
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             if (!grp) __builtin_amdgcn_s_barrier();        // stagger out: both groups are past their last MFMA
+            }
 #else
             for (int k = 0; k < nk; ++k, ++g) {
                 stamp(k, 0);
@@ -350,6 +394,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         }
                     }
                 }
+                if constexpr (EPI == EPI_BIAS_BF16) {      // folded LayerNorm-3 of the plain up-projection (grids other than 16 x 16)
+                    if (k == 1 && p.row_stats && wid < 2) {
+                        int r0s = m0 + wid * 128 + lane * 2;                     // 2 rows (16 B) per lane, clamped at the matrix end
+                        r0s = r0s + 1 < p.M ? r0s : (p.M >= 2 ? p.M - 2 : 0);
+                        const char* src = reinterpret_cast<const char*>(p.row_stats + r0s);
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::PLAINRS_OFF + wid * 1024), 16, 0, 0);
+                    }
+                }
                 if constexpr (EPI == EPI_UP_DWCONV || EPI == EPI_UP_DWCONV2) {
                     // folded LayerNorm-3: the tile's 256 (mean, rstd) pairs travel by DMA into LDS behind the image while
                     // the K loop runs (K-step 1: every wave is past the previous tile's epilogue, which read them)
@@ -357,6 +409,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     if (k == 1 && p.row_stats && wid < 2) {
                         const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
                         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + RS_OFF + wid * 1024), 16, 0, 0);
+                    }
+                    if constexpr (EPI == EPI_UP_DWCONV2) {      // waves 2 / 3: c1 / bias of the tile's columns
+                        if (k == 1 && (wid == 3 || (wid == 2 && p.row_stats))) {
+                            const float* src = (wid == 2 ? p.ln_c1 : p.bias) + n0 + lane * 4;
+                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::CB2_OFF + (wid - 2) * 1024), 16, 0, 0);
+                        }
                     }
                 }
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
@@ -586,35 +644,45 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 float cst[G::TN], bst[G::TN];
 #pragma unroll
                 for (int j = 0; j < G::TN; ++j) {
-                    const int c = n0 + wn * 64 + j * 32 + l31;
-                    bst[j] = p.bias[c];
-                    cst[j] = ln3 ? p.ln_c1[c] : 0.f;
+                    const int cl = wn * 64 + j * 32 + l31;
+                    bst[j] = *reinterpret_cast<const float*>(smem + G::CB2_OFF + 1024 + cl * 4);
+                    cst[j] = ln3 ? *reinterpret_cast<const float*>(smem + G::CB2_OFF + cl * 4) : 0.f;
                 }
                 if (!TLD_EPI_BIT(8))
 #pragma unroll
-                for (int i = 0; i < G::TM; ++i)
+                for (int i = 0; i < G::TM; ++i) {
+                    // (mean, rstd) of this lane's 16 tokens of the MFMA row-tile: all eight 16-B reads first, one wait
+                    float4 sv[8];
+                    if (ln3) {
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const int tok0 = wm * G::WROWS + i * 32 + 8 * rq + 4 * hi;
+                            sv[2 * rq] = *reinterpret_cast<const float4*>(smem + G::ROWSTAT2_OFF + tok0 * 8);
+                            sv[2 * rq + 1] = *reinterpret_cast<const float4*>(smem + G::ROWSTAT2_OFF + tok0 * 8 + 16);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q8 = 0; q8 < 8; ++q8) sv[q8] = make_float4(0.f, 1.f, 0.f, 1.f);
+                    }
 #pragma unroll
                     for (int rq = 0; rq < 4; ++rq) {
                         const int tok0 = wm * G::WROWS + i * 32 + 8 * rq + 4 * hi;          // 4 consecutive tokens
-                        float rs[4] = {1.f, 1.f, 1.f, 1.f}, nm[4] = {0.f, 0.f, 0.f, 0.f};
-                        if (ln3) {
-                            const float4 s01 = *reinterpret_cast<const float4*>(smem + G::ROWSTAT2_OFF + tok0 * 8);
-                            const float4 s23 = *reinterpret_cast<const float4*>(smem + G::ROWSTAT2_OFF + tok0 * 8 + 16);
-                            rs[0] = s01.y; nm[0] = -s01.y * s01.x; rs[1] = s01.w; nm[1] = -s01.w * s01.z;
-                            rs[2] = s23.y; nm[2] = -s23.y * s23.x; rs[3] = s23.w; nm[3] = -s23.w * s23.z;
-                        }
+                        const float4 s01 = sv[2 * rq], s23 = sv[2 * rq + 1];
+                        const float rs0 = s01.y, rs1 = s01.w, rs2 = s23.y, rs3 = s23.w;
+                        const float nm0 = -s01.y * s01.x, nm1 = -s01.w * s01.z, nm2 = -s23.y * s23.x, nm3 = -s23.w * s23.z;
 #pragma unroll
                         for (int j = 0; j < G::TN; ++j) {
                             bf16x2 lo, hi2;
-                            lo[0] = (bf16)fmaf(rs[0], acc[i][j][rq * 4 + 0], fmaf(nm[0], cst[j], bst[j]));
-                            lo[1] = (bf16)fmaf(rs[1], acc[i][j][rq * 4 + 1], fmaf(nm[1], cst[j], bst[j]));
-                            hi2[0] = (bf16)fmaf(rs[2], acc[i][j][rq * 4 + 2], fmaf(nm[2], cst[j], bst[j]));
-                            hi2[1] = (bf16)fmaf(rs[3], acc[i][j][rq * 4 + 3], fmaf(nm[3], cst[j], bst[j]));
+                            lo[0] = (bf16)fmaf(rs0, acc[i][j][rq * 4 + 0], fmaf(nm0, cst[j], bst[j]));
+                            lo[1] = (bf16)fmaf(rs1, acc[i][j][rq * 4 + 1], fmaf(nm1, cst[j], bst[j]));
+                            hi2[0] = (bf16)fmaf(rs2, acc[i][j][rq * 4 + 2], fmaf(nm2, cst[j], bst[j]));
+                            hi2[1] = (bf16)fmaf(rs3, acc[i][j][rq * 4 + 3], fmaf(nm3, cst[j], bst[j]));
                             char* dst = H + (tok0 >> 1) * G::IMG2_PITCH + (wn * 64 + j * 32 + l31) * 4;
                             *reinterpret_cast<bf16x2*>(dst) = lo;
                             *reinterpret_cast<bf16x2*>(dst + G::IMG2_PITCH) = hi2;
                         }
                     }
+                }
                 __builtin_amdgcn_s_barrier();
                 if (!TLD_EPI_BIT(4)) {
                     const int cq = threadIdx.x & 63;                     // channel quad
@@ -804,15 +872,24 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             for (int rq = 0; rq < 4; ++rq) {
                                 const int cl = j * 32 + 8 * rq + 4 * e_hi;
                                 float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                                float rs_ = 1.0f;
                                 if constexpr (EPI == EPI_BIAS_BF16) {
                                     const int cg = col0 + cl < p.N ? col0 + cl : 0;
                                     bv = *reinterpret_cast<const float4*>(p.bias + cg);
+                                    if (p.row_stats) {      // LayerNorm-3 folded in: rstd_m (acc - mean_m c1[n]) + b1[n], lane = token row
+                                        const float2 st2 = *reinterpret_cast<const float2*>(smem + G::PLAINRS_OFF + (wm * G::WROWS + i * 32 + e_l31) * 8);
+                                        const float4 c4 = *reinterpret_cast<const float4*>(p.ln_c1 + cg);
+                                        rs_ = st2.y;
+                                        const float nm_ = -st2.y * st2.x;
+                                        bv.x = fmaf(nm_, c4.x, bv.x); bv.y = fmaf(nm_, c4.y, bv.y);
+                                        bv.z = fmaf(nm_, c4.z, bv.z); bv.w = fmaf(nm_, c4.w, bv.w);
+                                    }
                                 }
                                 bf16x4 pk;
-                                pk[0] = (bf16)(acc[i][j][rq * 4 + 0] + bv.x);
-                                pk[1] = (bf16)(acc[i][j][rq * 4 + 1] + bv.y);
-                                pk[2] = (bf16)(acc[i][j][rq * 4 + 2] + bv.z);
-                                pk[3] = (bf16)(acc[i][j][rq * 4 + 3] + bv.w);
+                                pk[0] = (bf16)fmaf(rs_, acc[i][j][rq * 4 + 0], bv.x);
+                                pk[1] = (bf16)fmaf(rs_, acc[i][j][rq * 4 + 1], bv.y);
+                                pk[2] = (bf16)fmaf(rs_, acc[i][j][rq * 4 + 2], bv.z);
+                                pk[3] = (bf16)fmaf(rs_, acc[i][j][rq * 4 + 3], bv.w);
                                 *reinterpret_cast<bf16x4*>(ws + e_l31 * P + ((((cl >> 3) ^ (e_l31 & 7)) << 4) | ((cl & 7) << 1))) = pk;
                             }
 #pragma unroll
@@ -890,7 +967,8 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     do {                                                                                              \
         constexpr int lds = (E) == EPI_UP_DWCONV && G::UPDW_LDS > G::LDS_BYTES ? G::UPDW_LDS                     \
                             : ((E) == EPI_UP_DWCONV2 ? G::UPDW2_LDS                                   \
-                            : ((E) == EPI_QKV_LN ? G::QKVLN_LDS : G::LDS_BYTES));                     \
+                            : ((E) == EPI_QKV_LN ? G::QKVLN_LDS                                        \
+                            : ((E) == EPI_BIAS_BF16 ? G::PLAINLN_LDS : G::LDS_BYTES)));               \
         static bool once = false;                                                                     \
         if (!once) {                                                                                  \
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E>),                \

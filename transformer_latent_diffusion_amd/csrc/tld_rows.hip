@@ -790,45 +790,57 @@ __global__ __launch_bounds__(256) void dwconv_gelu_tiled_kernel(const bf16* __re
     }
     const int cq = threadIdx.x & 15;
     const int c0 = cc * DW_CB + cq * 4;
-    float4 w[9];
+    // packed-fp32 arithmetic: channel pairs {c0, c0+1} and {c0+2, c0+3} ride in f32x2 registers.  w9c / bias are the
+    // HALVED tables (the conv delivers y = x / 2 and the GELU is evaluated in its half-argument form, see tld_common.h)
+    f32x2 w[9][2], bs[2];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w[k] = *reinterpret_cast<const float4*>(w9c + (size_t)k * C + c0);
-    const float4 bs = *reinterpret_cast<const float4*>(bias + c0);
+    for (int k = 0; k < 9; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(w9c + (size_t)k * C + c0);
+        w[k][0] = f32x2{t.x, t.y}; w[k][1] = f32x2{t.z, t.w};
+    }
+    {
+        const float4 t = *reinterpret_cast<const float4*>(bias + c0);
+        bs[0] = f32x2{t.x, t.y}; bs[1] = f32x2{t.z, t.w};
+    }
     __syncthreads();
     const int li = threadIdx.x >> 4;                       // output row inside the tile (0..15)
     const int gi = ty * T + li;
     if (gi >= g) return;
-    auto col = [&](int lj, float4 (&c)[3]) {               // lj: halo-tile column index 0..17
+    auto col = [&](int lj, f32x2 (&c)[3][2]) {             // lj: halo-tile column index 0..17
 #pragma unroll
         for (int du = 0; du < 3; ++du) {
             const bf16x4 v = *reinterpret_cast<const bf16x4*>(tile + ((li + du) * TP + lj) * 128 + cq * 8);
-            c[du] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+            c[du][0] = f32x2{(float)v[0], (float)v[1]};
+            c[du][1] = f32x2{(float)v[2], (float)v[3]};
         }
     };
-    float4 cL[3], cM[3], cR[3];
-    col(0, cL); col(1, cM);
-    for (int lj = 0; lj < T; ++lj) {
-        const int gj = tx * T + lj;
-        if (gj >= g) break;
-        col(lj + 2, cR);
-        float4 part[3];
+    bf16* dst = out + ((size_t)b * g * g + (size_t)gi * g + (size_t)tx * T) * C + c0;
+    const int ncols = g - tx * T < T ? g - tx * T : T;     // (a multiple of the tile width for every supported grid)
+    auto emit = [&](const f32x2 (&L)[3][2], const f32x2 (&Mc)[3][2], const f32x2 (&R)[3][2], int lj) {
+        f32x2 a[2] = {bs[0], bs[1]};
 #pragma unroll
-        for (int du = 0; du < 3; ++du) {
-            const float4 w0 = w[du * 3 + 0], w1 = w[du * 3 + 1], w2 = w[du * 3 + 2];
-            part[du].x = fmaf(w2.x, cR[du].x, fmaf(w1.x, cM[du].x, w0.x * cL[du].x));
-            part[du].y = fmaf(w2.y, cR[du].y, fmaf(w1.y, cM[du].y, w0.y * cL[du].y));
-            part[du].z = fmaf(w2.z, cR[du].z, fmaf(w1.z, cM[du].z, w0.z * cL[du].z));
-            part[du].w = fmaf(w2.w, cR[du].w, fmaf(w1.w, cM[du].w, w0.w * cL[du].w));
-        }
+        for (int du = 0; du < 3; ++du)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                a[h2] = __builtin_elementwise_fma(w[du * 3 + 0][h2], L[du][h2], a[h2]);
+                a[h2] = __builtin_elementwise_fma(w[du * 3 + 1][h2], Mc[du][h2], a[h2]);
+                a[h2] = __builtin_elementwise_fma(w[du * 3 + 2][h2], R[du][h2], a[h2]);
+            }
+        a[0] = gelu_erf_fast2_half(a[0]); a[1] = gelu_erf_fast2_half(a[1]);
         bf16x4 o;
-        o[0] = (bf16)TLD_DW_GELU((part[0].x + part[1].x) + (part[2].x + bs.x));
-        o[1] = (bf16)TLD_DW_GELU((part[0].y + part[1].y) + (part[2].y + bs.y));
-        o[2] = (bf16)TLD_DW_GELU((part[0].z + part[1].z) + (part[2].z + bs.z));
-        o[3] = (bf16)TLD_DW_GELU((part[0].w + part[1].w) + (part[2].w + bs.w));
-        *reinterpret_cast<bf16x4*>(out + ((size_t)b * g * g + (size_t)gi * g + gj) * C + c0) = o;
-#pragma unroll
-        for (int du = 0; du < 3; ++du) { cL[du] = cM[du]; cM[du] = cR[du]; }
+        o[0] = (bf16)a[0][0]; o[1] = (bf16)a[0][1]; o[2] = (bf16)a[1][0]; o[3] = (bf16)a[1][1];
+        if (lj < ncols) *reinterpret_cast<bf16x4*>(dst + (size_t)lj * C) = o;
+    };
+    // the window rotates through three named column buffers (no register copies); 16 = 5 x 3 + 1 positions
+    f32x2 c0v[3][2], c1v[3][2], c2v[3][2];
+    col(0, c0v); col(1, c1v);
+    int lj = 0;
+    for (; lj + 3 <= T; lj += 3) {
+        col(lj + 2, c2v); emit(c0v, c1v, c2v, lj);
+        col(lj + 3, c0v); emit(c1v, c2v, c0v, lj + 1);
+        col(lj + 4, c1v); emit(c2v, c0v, c1v, lj + 2);
     }
+    col(lj + 2, c2v); emit(c0v, c1v, c2v, lj);             // lj == 15
 }
 
 }  // namespace
@@ -905,12 +917,12 @@ void launch_update(const UpdateParams& p, hipStream_t s) {
     hipLaunchKernelGGL(update_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
 }
 
-void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c, const float* bias, int batch, int grid,
-                        int channels, hipStream_t s) {
-    if (grid > 16) {        // spatially tiled variant (halo in LDS)
+void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c, const float* bias, const float* w9c_half,
+                        const float* bias_half, int batch, int grid, int channels, hipStream_t s) {
+    if (grid > 16) {        // spatially tiled variant (halo in LDS); takes the halved tables
         const int tiles = (grid + 15) / 16;
         hipLaunchKernelGGL(dwconv_gelu_tiled_kernel, dim3((unsigned)(batch * tiles * tiles * (channels / DW_CB))),
-                           dim3(256), 0, s, in, out, w9c, bias, batch, grid, channels);
+                           dim3(256), 0, s, in, out, w9c_half, bias_half, batch, grid, channels);
         return;
     }
     const int lds = grid * grid * 128;
