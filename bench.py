@@ -41,9 +41,14 @@ GFLOP_BY_IMAGE_SIZE = {32: 46.163, 64: 213.466, 128: 1317.543}   # Appendix B, p
 MFMA_PEAK_TFLOPS = 2500.0          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def gemm_flops(cls, M, d):
+def class_flops(cls, M, d, ntok, n_layers):
+    """Algorithmic flops of one launch of a profiled kernel class (average over the launches of a forward: block 0's
+    QKV GEMM and attention run on the un-doubled batch when the CFG halves share it)."""
+    if cls == "attention":
+        return 4.0 * M * ntok * d * (n_layers - 0.5) / n_layers            # QK^T and PV: 2 x 2 M ntok d
     n, k = {"gemm_qkv": (3 * d, d), "gemm_up": (4 * d, d), "gemm_down": (d, 4 * d)}[cls]
-    return 2.0 * M * n * k
+    f = 2.0 * M * n * k
+    return f * (n_layers - 0.5) / n_layers if cls == "gemm_qkv" else f
 
 
 def pmc_traffic(cls):
@@ -52,9 +57,10 @@ def pmc_traffic(cls):
     path = next((q for q in (os.path.join(REPO, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (2, 1)) if os.path.exists(q)), None)
     if path is None:
         return None, None
-    epis = {"gemm_qkv": (", 1>",), "gemm_up": (", 4>", ", 2>"), "gemm_down": (", 3>",)}[cls]   # 4 = up fused with dwconv+GELU
+    epis = {"gemm_qkv": (", 1>", ", 5>", ", 1,", ", 5,"), "gemm_up": (", 6>", ", 4>", ", 2>", ", 6,", ", 4,", ", 2,"),
+            "gemm_down": (", 3>", ", 3,"), "attention": ("attn",)}[cls]       # 4 / 6 = up-projection fused with dwconv + GELU
     for name, v in json.load(open(path)).items():
-        if "gemm256p_kernel" in name and any(e in name for e in epis):
+        if ("gemm256p_kernel" in name or cls == "attention") and any(e in name for e in epis):
             return v["hbm_bytes_per_launch"], f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)"
     return None, None
 
@@ -176,6 +182,8 @@ def main():
     ap.add_argument("--images-per-gpu", type=int, default=PER_GPU_IMAGES)
     ap.add_argument("--image-size", type=int, default=32, choices=(32, 64, 128),
                     help="latent size: 32 = C1/C2 (headline), 64 = C3 shape, 128 = C4 shape (bf16)")
+    ap.add_argument("--gemm-dtype", default="bf16", choices=("bf16", "fp8"),
+                    help="operand type of the QKV / MLP GEMMs: bf16 (headline) or fp8 (MX-fp8, BASELINE config C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of the GEMM classes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
@@ -211,7 +219,7 @@ def main():
     gflop_fwd = GFLOP_BY_IMAGE_SIZE[S]
     ntok = (S // 2) ** 2
     sd = synth_state_dict(cfg, 5)
-    model = Denoiser(**asdict(cfg)).to(dev)
+    model = Denoiser(**asdict(cfg)).to(dev).set_gemm_dtype(args.gemm_dtype)
     model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     B = args.images_per_gpu
     model.reserve(2 * B)
@@ -231,7 +239,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    gemm_classes = ("gemm_qkv", "gemm_up", "gemm_down")
+    gemm_classes = ("gemm_qkv", "gemm_up", "gemm_down", "attention")
     for _ in range(args.warmup):
         out = one_step()
     fence()
@@ -272,8 +280,8 @@ def main():
             "metric": f"images/sec ({8 * S}px, 35-step CFG sampling), denoiser only",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{ {32: 'C1', 64: 'C3-shape', 128: 'C4-shape (bf16)'}[S]}: 100M-param denoiser (d=768, L=12), {S}x{S}x4 latents, 35 steps + CFG 6, "
+            "dtype": "bf16" if args.gemm_dtype == "bf16" else "fp8-gemm/bf16", "data": "synthetic",
+            "config": {"workload": f"{ {32: 'C1', 64: 'C3', 128: 'C4'}[S]}{' (MX-fp8 QKV/MLP GEMMs)' if args.gemm_dtype == 'fp8' else ''}: 100M-param denoiser (d=768, L=12), {S}x{S}x4 latents, 35 steps + CFG 6, "
                                    f"DPM-Solver++(2M), {B} images/GPU (model batch {2 * B})",
                        "images_per_gpu": B, "global_batch": total, "n_iter": N_ITER, "class_guidance": CFG,
                        "parallelism": f"dp{world} (sample-sharded, one all-gather)" if world > 1 else "single GPU"},
@@ -292,20 +300,22 @@ def main():
             dom = dom_cls
             ms, n = prof[dom]
             avg_s = ms / max(n, 1) / 1e3
-            ach = gemm_flops(dom, M, cfg.embed_dim) / avg_s / 1e12
-            tot_f = sum(gemm_flops(c, M, cfg.embed_dim) * prof[c][1] for c in prof)
+            fl = lambda c: class_flops(c, M, cfg.embed_dim, ntok, cfg.n_layers)
+            ach = fl(dom) / avg_s / 1e12
+            tot_f = sum(fl(c) * prof[c][1] for c in prof)
             tot_t = sum(prof[c][0] for c in prof) / 1e3
             traffic, traffic_src = pmc_traffic(dom)
+            # dense MFMA peak of the dominant class's operand type (MI355X_MICROARCH.md): bf16 2.5 PF, MX-fp8 5 PF
+            peak = 2 * MFMA_PEAK_TFLOPS if (args.gemm_dtype == "fp8" and dom != "attention") else MFMA_PEAK_TFLOPS
             line["roofline"] = {
-                "bound": "mfma", "kernel": f"gemm256p_kernel<{dom}>", "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_ms": ms / max(n, 1), "launches": n,
-                "flops_per_launch": gemm_flops(dom, M, cfg.embed_dim),
-                "all_gemm_classes": {c: {"avg_ms": prof[c][0] / max(prof[c][1], 1), "launches": prof[c][1],
-                                         "tflops": gemm_flops(c, M, cfg.embed_dim) / (prof[c][0] / max(prof[c][1], 1) / 1e3) / 1e12}
-                                     for c in prof},
-                "note": "dominant class timed with HIP events inside the timed region; the other classes on one untimed pass",
-                "gemm_aggregate_tflops": tot_f / tot_t / 1e12,
+                "bound": "mfma", "kernel": "attn kernel" if dom == "attention" else f"gemm256p_kernel<{dom}>", "achieved": ach,
+                "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_ms": ms / max(n, 1), "launches": n, "flops_per_launch": fl(dom),
+                "all_mfma_classes": {c: {"avg_ms": prof[c][0] / max(prof[c][1], 1), "launches": prof[c][1],
+                                         "tflops": fl(c) / (prof[c][0] / max(prof[c][1], 1) / 1e3) / 1e12} for c in prof},
+                "note": "dominant class timed with HIP events inside the timed region; the other classes on one untimed pass; "
+                        "flops_per_launch is the average over a forward's launches (block 0 runs on the un-doubled batch)",
+                "mfma_aggregate_tflops": tot_f / tot_t / 1e12,
             }
         if world == 1 and not args.no_cpu_baseline and S == 32:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)

@@ -67,6 +67,11 @@ TLD_API int tld_engine_load_tensor(tld_engine* e, const char* key, const void* h
  * fails with TLD_ERR_STATE and names the first missing key if the state_dict was incomplete. */
 TLD_API int tld_engine_finalize_weights(tld_engine* e);
 
+/* Operand type of the QKV / MLP GEMMs: 0 = bf16 (default), 1 = MX-fp8 (OCP e4m3 elements with one E8M0 scale per 32
+ * K-elements, v_mfma_scale_f32_32x32x64_f8f6f4).  Call between tld_engine_create and tld_engine_finalize_weights.
+ * Not in the reference (its model_dtype is fp32 / fp16 / bf16, tld/configs.py:33-37): BASELINE config C4. */
+TLD_API int tld_engine_set_gemm_dtype(tld_engine* e, int32_t dtype);
+
 /* Denoiser.forward(x, noise_level, label) -- tld/denoiser.py:116-126 (called at tld/diffusion.py:97-101).
  *   x      [batch, C, S, S]     device, io_dtype
  *   noise  [batch, 1]           device, io_dtype
@@ -102,6 +107,14 @@ TLD_API int tld_engine_read_stage(tld_engine* e, const char* name, float* host_o
  * device inputs, fp32 device output.  K % 64 == 0. */
 TLD_API int tld_debug_gemm_bf16(const void* a_bf16, const void* w_bf16, float* c_f32, int32_t M, int32_t N,
                         int32_t K, void* hip_stream);
+
+/* Test hooks of the MX-fp8 path.  quant_mx8: bf16 device matrix [M,K] -> e4m3 bytes [M,K] + E8M0 block scales laid out
+ * [K/128][M][4] (device); quant_mx8_host: the weight-side quantiser (fp32 host matrix, host outputs, no GPU needed);
+ * gemm_mx8: C[M,N] = dequant(A) . dequant(W)^T in fp32 from such operands (device).  K % 128 == 0, M % 4 == N % 4 == 0. */
+TLD_API int tld_debug_quant_mx8(const void* in_bf16, void* out_e4m3, void* out_scale, int32_t M, int32_t K, void* hip_stream);
+TLD_API int tld_debug_quant_mx8_host(const float* w, int32_t rows, int32_t K, void* out_e4m3, void* out_scale);
+TLD_API int tld_debug_gemm_mx8(const void* a_e4m3, const void* a_scale, const void* w_e4m3, const void* w_scale, float* c_f32,
+                               int32_t M, int32_t N, int32_t K, void* hip_stream);
 
 /* Test/bench hook: time the engine's GEMM on self-allocated, pseudo-randomly filled device buffers.
  * epilogue: 0 fp32 out, 1 QKV (q|k row-major + V^T; N = 3*d, ntok tokens per sample), 2 bias+bf16,

@@ -12,6 +12,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // Residual stream dtype: bf16, as in the reference's own bf16 mode (x never leaves bf16 there either).  All
@@ -213,6 +214,12 @@ struct GemmParams {
     // bias = up_b + beta3 . Wup^T, and the image write applies  rstd_m (acc - mean_m c1[n]) + bias[n]
     const float2* row_stats;      // [M] (mean, rstd) per row; null: A is already normalized
     const float* ln_c1;           // [N] column sums of the gamma-scaled bf16 weights
+    // MX-fp8 operands (f8 != 0): A and W hold OCP e4m3 bytes ([M,K] / [N,K], K contiguous, lda / ldw in elements = bytes),
+    // a_scale / w_scale one E8M0 byte per 32 K-elements, laid out [K/128][rows][4] so that a tile's scales of one 128-wide
+    // K-step are contiguous.  K % 128 == 0, M % 4 == 0, N % 4 == 0.  Epilogues: EPI_F32, EPI_QKV, EPI_BIAS_BF16, EPI_BIAS_RESID.
+    int f8;
+    const uint8_t* a_scale;
+    const uint8_t* w_scale;
     unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0
     int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop
@@ -220,6 +227,10 @@ struct GemmParams {
 };
 
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s);
+
+// MX-fp8 quantisation of a GEMM operand (tld_quant.hip): e4m3 elements [rows, K] + E8M0 block scales [K/128][rows][4]
+void launch_quant_mx8(const bf16* in, uint8_t* out, uint8_t* scale, int M, int K, hipStream_t s);
+void quant_mx8_host(const float* w, int rows, int K, uint8_t* out, uint8_t* scale);
 constexpr int kLnSlots = 8;
 // slots an EPI_BIAS_RESID launch of width N writes for every batch size (0: shape not supported -> keep the LN kernel)
 int gemm_resid_stat_slots(int N);

@@ -71,6 +71,8 @@ struct Layer {
     float *up_b = nullptr, *dw_w9c = nullptr, *dw_b = nullptr, *down_b = nullptr;
     float *dw_w9c_half = nullptr, *dw_b_half = nullptr;   // 0.5 x (exact): operands of the fused up-projection epilogue
     uint32_t* dw_wpk = nullptr;                           // the halved taps as packed bf16 pairs [3][4][hid] (EPI_UP_DWCONV2)
+    // MX-fp8 GEMM mode (tld_engine_set_gemm_dtype): e4m3 weights + E8M0 block scales [K/128][N][4]
+    uint8_t *qkv_w8 = nullptr, *qkv_s8 = nullptr, *up_w8 = nullptr, *up_s8 = nullptr, *down_w8 = nullptr, *down_s8 = nullptr;
     bf16 *up_wf = nullptr;                                // bf16(gamma3 (.) Wup): LayerNorm-3 folded into the up-projection
     float *up_c1 = nullptr, *up_b1 = nullptr;             // [hid] column sums of up_wf; up_b + beta3 . Wup^T
     float *n1_w = nullptr, *n1_b = nullptr, *n2_w = nullptr, *n2_b = nullptr, *n3_w = nullptr, *n3_b = nullptr;
@@ -88,6 +90,8 @@ struct tld_engine {
     bool finalized = false;
     bool fuse_dwconv = true;            // TLD_FUSE_DWCONV=0 selects the two-kernel path (A/B testing)
     bool updw_v2 = true;                // TLD_UPDW_V2=0: first form of the fused depthwise epilogue (fp32 taps, A/B testing)
+    bool fp8 = false;                   // QKV / MLP GEMMs on MX-fp8 operands (BASELINE config C4); set before finalize
+    uint8_t *a8 = nullptr, *as8 = nullptr;   // fp8 mode: quantised A operand [M, hid] and its block scales [hid/128][M][4]
     std::map<std::string, HostTensor> host;
     std::vector<void*> allocs;
     int64_t weight_bytes = 0;
@@ -291,6 +295,11 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             GemmParams g{};
             g.A = e->xn; g.lda = d; g.W = Ly.qkv_w; g.ldw = d; g.M = Ml; g.N = 3 * d; g.K = d;
             g.out_bf16 = e->qk; g.ldo = 2 * d; g.vt = e->vt; g.ntok = e->ntok; g.d = d;
+            if (e->fp8) {   // MX-fp8: quantise LN1(x) (one pass over [M, d]), then the e4m3 GEMM
+                launch_quant_mx8(e->xn, e->a8, e->as8, Ml, d, s);
+                g.f8 = 1; g.A = reinterpret_cast<const bf16*>(e->a8); g.W = reinterpret_cast<const bf16*>(Ly.qkv_w8);
+                g.a_scale = e->as8; g.w_scale = Ly.qkv_s8;
+            }
 #ifdef TLD_RESID_BF16
             if (fold1) {    // raw residual rows x gamma-scaled weights; partial sums from embed (block 0) / the down projection
                 g.A = half ? xe : e->x; g.W = Ly.qkv_wf; g.ln_stats = e->ln_stats; g.ln_slots = l == 0 ? 2 : ln_slots;
@@ -346,6 +355,11 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
                 GemmParams g{};
                 g.A = e->xn; g.lda = d; g.W = Ly.up_w; g.ldw = d; g.M = M; g.N = e->hid; g.K = d;
                 g.out_bf16 = e->hid1; g.ldo = e->hid; g.bias = Ly.up_b;
+                if (e->fp8) {
+                    launch_quant_mx8(e->xn, e->a8, e->as8, M, d, s);
+                    g.f8 = 1; g.A = reinterpret_cast<const bf16*>(e->a8); g.W = reinterpret_cast<const bf16*>(Ly.up_w8);
+                    g.a_scale = e->as8; g.w_scale = Ly.up_s8;
+                }
 #ifdef TLD_RESID_BF16
                 if (fold3) {
                     g.A = e->x; g.W = Ly.up_wf; g.bias = Ly.up_b1; g.ln_c1 = Ly.up_c1; g.row_stats = e->row_stats;
@@ -364,6 +378,11 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             g.A = e->hid2; g.lda = e->hid; g.W = Ly.down_w; g.ldw = e->hid; g.M = M; g.N = d; g.K = e->hid;
             g.bias = Ly.down_b; g.resid = e->x; g.ldr = d;
             g.stats_out = (fold1 && l + 1 < e->L) ? e->ln_stats : nullptr;
+            if (e->fp8) {
+                launch_quant_mx8(e->hid2, e->a8, e->as8, M, e->hid, s);
+                g.f8 = 1; g.A = reinterpret_cast<const bf16*>(e->a8); g.W = reinterpret_cast<const bf16*>(Ly.down_w8);
+                g.a_scale = e->as8; g.w_scale = Ly.down_s8;
+            }
             launch_gemm(g, EPI_BIAS_RESID, s);
         }
         if (l == 0) if (int rc = capture(e, "blk0_mlp", e->x, (size_t)M * d, s)) return rc;
@@ -542,6 +561,22 @@ int tld_engine_finalize_weights(tld_engine* e) {
             HIP_TRY(hipMemcpy(Ly.qkv_b1, b1.data(), b1.size() * 4, hipMemcpyHostToDevice));
             e->weight_bytes += (int64_t)wf.size() * 2 + (int64_t)c1.size() * 8;
         }
+        if (e->fp8) {
+            struct Q { const char* key; int64_t rows, K; uint8_t** w; uint8_t** sc; };
+            const Q qs[3] = {{"self_attention.qkv_linear.weight", 3 * d, d, &Ly.qkv_w8, &Ly.qkv_s8},
+                             {"mlp.mlp.0.weight", hid, d, &Ly.up_w8, &Ly.up_s8},
+                             {"mlp.mlp.3.weight", d, hid, &Ly.down_w8, &Ly.down_s8}};
+            for (const Q& q : qs) {
+                const std::vector<float>& W = e->host[LK(q.key)].data;
+                std::vector<uint8_t> w8((size_t)(q.rows * q.K)), s8((size_t)(q.rows * q.K / 32));
+                quant_mx8_host(W.data(), (int)q.rows, (int)q.K, w8.data(), s8.data());
+                if (int rc = dev_alloc(e, q.w, w8.size())) return rc;
+                if (int rc = dev_alloc(e, q.sc, s8.size())) return rc;
+                HIP_TRY(hipMemcpy(*q.w, w8.data(), w8.size(), hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(*q.sc, s8.data(), s8.size(), hipMemcpyHostToDevice));
+                e->weight_bytes += (int64_t)(w8.size() + s8.size());
+            }
+        }
         if (int rc = upload_f32(e, LK("norm2.weight"), &Ly.n2_w, d)) return rc;
         if (int rc = upload_f32(e, LK("norm2.bias"), &Ly.n2_b, d)) return rc;
         if (int rc = upload_f32(e, LK("norm3.weight"), &Ly.n3_w, d)) return rc;
@@ -635,6 +670,10 @@ int tld_engine_finalize_weights(tld_engine* e) {
     if (int rc = dev_alloc(e, &e->att, M * d)) return rc;
     if (int rc = dev_alloc(e, &e->hid1, M * hid)) return rc;
     if (int rc = dev_alloc(e, &e->hid2, M * hid)) return rc;
+    if (e->fp8) {
+        if (int rc = dev_alloc(e, &e->a8, M * hid)) return rc;
+        if (int rc = dev_alloc(e, &e->as8, M * hid / 32 + 1024)) return rc;
+    }
     if (int rc = dev_alloc(e, &e->io_x, B2 * e->img)) return rc;
     if (int rc = dev_alloc(e, &e->io_out, B2 * e->img)) return rc;
     if (int rc = dev_alloc(e, &e->io_sigma, B2)) return rc;
@@ -851,6 +890,52 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     }
     hipEventDestroy(a); hipEventDestroy(b);
     hipFree(A); hipFree(W); hipFree(out); hipFree(vt); hipFree(bias); hipFree(res); hipFree(dww);
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
+int tld_engine_set_gemm_dtype(tld_engine* e, int32_t dtype) {
+    if (!e) return fail(TLD_ERR_INVALID, "null engine");
+    if (e->finalized) return fail(TLD_ERR_STATE, "the GEMM operand type must be chosen before tld_engine_finalize_weights");
+    if (dtype != 0 && dtype != 1) return fail(TLD_ERR_INVALID, "gemm dtype %d: 0 = bf16, 1 = MX-fp8 (e4m3 + E8M0 block scales)", dtype);
+    if (dtype == 1) {
+#ifndef TLD_RESID_BF16
+        return fail(TLD_ERR_INVALID, "the fp8 GEMM mode exists in the bf16-residual build only");
+#endif
+        if (e->d % 128 || e->hid % 128) return fail(TLD_ERR_INVALID, "fp8 GEMMs need embed_dim and hidden width multiples of 128");
+        e->fp8 = true;
+        // activations are quantised from the separately written LayerNorm / GELU outputs: no folds, no fused depthwise epilogue
+        e->fold_ln1 = false; e->fold_ln3 = false; e->fuse_dwconv = false;
+    } else {
+        e->fp8 = false;
+    }
+    return TLD_OK;
+}
+
+int tld_debug_quant_mx8_host(const float* w, int32_t rows, int32_t K, void* out_e4m3, void* out_scale) {
+    if (!w || !out_e4m3 || !out_scale || rows <= 0 || K <= 0 || K % 128) return fail(TLD_ERR_INVALID, "bad argument (K %% 128 == 0)");
+    quant_mx8_host(w, rows, K, static_cast<uint8_t*>(out_e4m3), static_cast<uint8_t*>(out_scale));
+    return TLD_OK;
+}
+
+int tld_debug_quant_mx8(const void* in_bf16, void* out_e4m3, void* out_scale, int32_t M, int32_t K, void* hip_stream) {
+    if (!in_bf16 || !out_e4m3 || !out_scale || M <= 0 || K <= 0 || K % 128) return fail(TLD_ERR_INVALID, "bad argument (K %% 128 == 0)");
+    launch_quant_mx8(static_cast<const bf16*>(in_bf16), static_cast<uint8_t*>(out_e4m3), static_cast<uint8_t*>(out_scale), M, K,
+                     static_cast<hipStream_t>(hip_stream));
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
+int tld_debug_gemm_mx8(const void* a_e4m3, const void* a_scale, const void* w_e4m3, const void* w_scale, float* c, int32_t M,
+                       int32_t N, int32_t K, void* hip_stream) {
+    if (!a_e4m3 || !a_scale || !w_e4m3 || !w_scale || !c) return fail(TLD_ERR_INVALID, "null argument");
+    if (K % 128 || K <= 0 || M <= 0 || N <= 0 || M % 4 || N % 4) return fail(TLD_ERR_INVALID, "need K %% 128 == 0, M %% 4 == 0, N %% 4 == 0");
+    GemmParams g{};
+    g.f8 = 1;
+    g.A = static_cast<const bf16*>(a_e4m3); g.lda = K; g.W = static_cast<const bf16*>(w_e4m3); g.ldw = K;
+    g.a_scale = static_cast<const uint8_t*>(a_scale); g.w_scale = static_cast<const uint8_t*>(w_scale);
+    g.M = M; g.N = N; g.K = K; g.c_f32 = c; g.ldc = N;
+    launch_gemm(g, EPI_F32, static_cast<hipStream_t>(hip_stream));
     HIP_TRY(hipGetLastError());
     return TLD_OK;
 }

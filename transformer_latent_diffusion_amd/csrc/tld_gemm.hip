@@ -105,9 +105,19 @@ struct G256P : G256<BN> {
     static constexpr int SCRATCH = 4608;             // per-wave epilogue scratch (8 x 4608 <= one stage)
 };
 
-template <int BN, int EPI>
+// F8 = true: both operands are OCP e4m3 bytes with MX block scales (one E8M0 byte per 32 K-elements), multiplied by
+// v_mfma_scale_f32_32x32x64_f8f6f4 at twice the bf16 rate.  A 128-byte tile row is then 128 K-elements, so the DMA, the
+// LDS image, its swizzle and every epilogue are those of the bf16 kernel; what changes is the fragment (32 bytes per
+// lane: two 16-B reads), the MFMA, and a 1-KiB strip of scale bytes per operand and K-step that travels with the tile
+// (scale layout [K/128][rows][4], see GemmParams).  Used for BASELINE config C4 (QKV / MLP GEMMs in fp8).
+template <int BN, int EPI, bool F8 = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks) {
     using G = G256P<BN>;
+    using frag_t = std::conditional_t<F8, i32x8, bf16x8>;
+    constexpr int ESZ = F8 ? 1 : 2;                                     // operand bytes per element
+    constexpr int SC_OFF = G::LDS_BYTES;                                // F8: [stage][A scales 1 KiB | W scales 1 KiB] behind the stages
+    static_assert(!F8 || (EPI == EPI_F32 || EPI == EPI_QKV || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID), "fp8 epilogues");
+    static_assert(!F8 || TLD_KLOOP_STAGGER, "the fp8 path exists in the staggered K loop only");
     constexpr bool IS_QKV = EPI == EPI_QKV || EPI == EPI_QKV_LN, LN = EPI == EPI_QKV_LN;
     static_assert(8 * G::SCRATCH <= G::STAGE_BYTES, "epilogue scratch must fit in one stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     };
     if (my_tiles == 0) return;
 
-    const int nk = p.K / G::BK;
+    const int nk = p.K * ESZ / (G::BK * 2);                            // 128-byte K-steps
     // DMA addressing: a uniform 64-bit base (operand + K offset, SGPRs) plus one 32-bit byte offset per piece and
     // lane (row clamp, row pitch and the source-side swizzle), recomputed once per tile -- per K-step and piece the
     // only VALU work is the load itself.  (Operands are < 4 GiB: checked at launch.)
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             const int clog = (ln & 7) ^ ((r >> 1) & 7);
             int gr = tm0 + r;
             gr = gr < p.M ? gr : p.M - 1;
-            unsigned v = __umul24((unsigned)gr, (unsigned)(p.lda * 2)) + (unsigned)(clog * 16);   // rows, pitch < 2^24
+            unsigned v = __umul24((unsigned)gr, (unsigned)(p.lda * ESZ)) + (unsigned)(clog * 16);   // rows, pitch < 2^24
             asm volatile("" : "+v"(v));
             voffA[q2] = v;
         }
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             const int clog = (ln & 7) ^ ((r >> 1) & 7);
             int gr = tn0 + r;
             gr = gr < p.N ? gr : p.N - 1;
-            unsigned v = __umul24((unsigned)gr, (unsigned)(p.ldw * 2)) + (unsigned)(clog * 16);
+            unsigned v = __umul24((unsigned)gr, (unsigned)(p.ldw * ESZ)) + (unsigned)(clog * 16);
             asm volatile("" : "+v"(v));
             voffB[q2] = v;
         }
@@ -197,18 +207,48 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                              (lptr_t)(st + G::A_BYTES + (wid * G::B_PIECES + (q2 - G::A_PIECES)) * 1024), 16, 0, TLD_GLDS_AUX);
         }
     };
+    // F8: the block scales of one K-step -- 4 bytes per row, [K/128][rows][4] in memory, so a tile's strip is one
+    // contiguous KiB (16 B = 4 rows per lane) -- wave 0 brings A's, wave 1 W's
+    auto dma_scales = [&](int tm0, int tn0, int kstep, int stage) {
+        if constexpr (F8) {
+            if (wid < 2) {
+                const int rows = wid == 0 ? p.M : p.N;
+                int r = (wid == 0 ? tm0 : tn0) + lane * 4;
+                r = r + 3 < rows ? r : rows - 4;                       // (rows % 4 == 0: lanes of valid rows never clamp)
+                const uint8_t* src = (wid == 0 ? p.a_scale : p.w_scale) + ((size_t)kstep * rows + r) * 4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + SC_OFF + stage * 2048 + wid * 1024), 16, 0, 0);
+            }
+        }
+    };
     auto issue = [&](int m0, int n0, int g) {                 // K-step 0 of a tile, all pieces at once
         char* st = smem + (g & 1) * G::STAGE_BYTES;
         set_offsets(m0, n0);
 #pragma unroll
         for (int q2 = 0; q2 < G::A_PIECES + G::B_PIECES; ++q2) dma_piece(q2, 0, st);
+        dma_scales(m0, n0, 0, g & 1);
     };
-    auto load_frags = [&](const char* st, int ks, bf16x8 (&a)[G::TM], bf16x8 (&b)[G::TN]) {
-        const int kc = ks * 2 + hi;
+    // ks: 16-element k-slice (bf16: 4 per K-step) / 64-element k-slice (fp8: 2 per K-step)
+    auto load_frags = [&](const char* st, int ks, frag_t (&a)[G::TM], frag_t (&b)[G::TN]) {
+        if constexpr (!F8) {
+            const int kc = ks * 2 + hi;
 #pragma unroll
-        for (int i = 0; i < G::TM; ++i) a[i] = read_frag(st, wm * G::WROWS + i * 32 + l31, kc);
+            for (int i = 0; i < G::TM; ++i) a[i] = read_frag(st, wm * G::WROWS + i * 32 + l31, kc);
 #pragma unroll
-        for (int j = 0; j < G::TN; ++j) b[j] = read_frag(st + G::A_BYTES, wn * G::WCOLS + j * 32 + l31, kc);
+            for (int j = 0; j < G::TN; ++j) b[j] = read_frag(st + G::A_BYTES, wn * G::WCOLS + j * 32 + l31, kc);
+        } else {
+            // lane (row l31, half hi) holds K-elements [64 ks + 32 hi, +32) of its row: logical 16-B chunks c, c + 1
+            const int c = ks * 4 + hi * 2;
+            auto rd = [&](const char* base, int row) {
+                const int sw = (row >> 1) & 7;
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(base + row * 128 + ((c ^ sw) << 4));
+                const u32x4 hi4 = *reinterpret_cast<const u32x4*>(base + row * 128 + (((c + 1) ^ sw) << 4));
+                return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+            };
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i) a[i] = rd(st, wm * G::WROWS + i * 32 + l31);
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j) b[j] = rd(st + G::A_BYTES, wn * G::WCOLS + j * 32 + l31);
+        }
     };
 
     int m0, n0;
@@ -235,16 +275,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        bf16x8 a0[G::TM], b0[G::TN], a1[G::TM], b1[G::TN];
+        frag_t a0[G::TM], b0[G::TN], a1[G::TM], b1[G::TN];
+        int sca[G::TM], scb[G::TN];                 // F8: this K-step's scale dwords of the lane's rows (already shifted by 8 hi)
         auto kloop = [&](auto swp) {
             constexpr bool SW = decltype(swp)::value;
-            auto mma = [&](const bf16x8 (&a)[G::TM], const bf16x8 (&b)[G::TN]) {
+            auto mma = [&](const frag_t (&a)[G::TM], const frag_t (&b)[G::TN], auto slice) {
+                constexpr int S2 = decltype(slice)::value * 2;      // F8: scale byte of k-slice s is byte 2 s (+ hi, shifted in)
 #pragma unroll
                 for (int i = 0; i < G::TM; ++i)
 #pragma unroll
                     for (int j = 0; j < G::TN; ++j) {
-                        if constexpr (SW) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        if constexpr (F8) {
+                            if constexpr (SW) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[j], a[i], acc[i][j], 0, 0, S2, scb[j], S2, sca[i]);
+                            else acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i], b[j], acc[i][j], 0, 0, S2, sca[i], S2, scb[j]);
+                        } else {
+                            if constexpr (SW) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        }
                     }
             };
             // The DMA pieces of the next K-step are spread over the four MFMA groups of this step (a burst of
@@ -321,8 +368,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 if (k + 1 == nk && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
                 // NS k-slices per interval: 1 -> 8 intervals (barriers) per K-step with 8 (12) MFMAs each; 2 -> 4 intervals with
                 // 16 MFMAs each and two fragment sets (the 384-wide tile has no registers for a second set)
-                constexpr int NS = (BN == 384) ? 1 : TLD_KLOOP_NS;
-                constexpr int NI = 4 / NS;
+                constexpr int NS = (BN == 384 || F8) ? 1 : TLD_KLOOP_NS;
+                constexpr int NI = (F8 ? 2 : 4) / NS;
+                constexpr int NDMA = (NI + 1) / 2;                 // intervals that carry tile DMA
 #pragma unroll
                 for (int h = 0; h < NI; ++h) {
                     // ---- R interval   (optional s_memtime trace: 4 stamps per interval pair, see tld_debug_gemm_bench)
@@ -335,14 +383,27 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     stamp4(0);
                     load_frags(st, h * NS, a0, b0);
                     if constexpr (NS == 2) load_frags(st, h * NS + 1, a1, b1);
+                    if constexpr (F8) {
+                        if (h == 0) {       // this K-step's block scales: 4 bytes per row; half hi uses bytes hi and 2 + hi
+                            const char* sc = smem + SC_OFF + (g & 1) * 2048;
+#pragma unroll
+                            for (int i = 0; i < G::TM; ++i) sca[i] = *reinterpret_cast<const int*>(sc + (wm * G::WROWS + i * 32 + l31) * 4) >> (8 * hi);
+#pragma unroll
+                            for (int j = 0; j < G::TN; ++j) scb[j] = *reinterpret_cast<const int*>(sc + 1024 + (wn * G::WCOLS + j * 32 + l31) * 4) >> (8 * hi);
+                        }
+                    }
                     // tile DMA of the next K-step: early in the step, so that every piece has >= 2 intervals to land before
                     // the vmcnt(0) of the step's last interval (NS == 2: all in the first R interval; NS == 1: first two)
-                    if (h < 2 / NS && more && !p.dbg_no_dma) {
-                        constexpr int PER = NS == 2 ? NP : (NP + 1) / 2;
+                    if (h < NDMA && more && !p.dbg_no_dma) {
+                        constexpr int PER = (NP + NDMA - 1) / NDMA;
 #pragma unroll
                         for (int q2 = 0; q2 < NP; ++q2) {
                             if (q2 < h * PER || q2 >= (h + 1) * PER) continue;
                             dma_piece(q2, pkb, nst);
+                        }
+                        if (h == 0) {
+                            if (k + 1 < nk) dma_scales(m0, n0, k + 1, (g + 1) & 1);
+                            else dma_scales(m0n, n0n, 0, (g + 1) & 1);
                         }
                     }
                     if (h == NI - 1) wait_vmcnt<0>();
@@ -354,8 +415,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     stamp4(2);
                     // ---- M interval
                     __builtin_amdgcn_s_setprio(1);
-                    mma(a0, b0);
-                    if constexpr (NS == 2) mma(a1, b1);
+                    if constexpr (F8) {
+                        if (h == 0) mma(a0, b0, std::integral_constant<int, 0>{}); else mma(a0, b0, std::integral_constant<int, 1>{});
+                    } else {
+                        mma(a0, b0, std::integral_constant<int, 0>{});
+                        if constexpr (NS == 2) mma(a1, b1, std::integral_constant<int, 0>{});
+                    }
                     __builtin_amdgcn_s_setprio(0);
                     if (h == NI - 1) wait_vmcnt<0>();
                     stamp4(3);
@@ -437,28 +502,28 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     for (int ks = 0; ks < 4; ++ks) {
                         load_frags(st, ks, a0, b0);
                         pieces((ks * NP + 3) / 4, ((ks + 1) * NP + 3) / 4);
-                        mma(a0, b0);
+                        mma(a0, b0, std::integral_constant<int, 0>{});
                     }
                     continue;
                 }
                 load_frags(st, 0, a0, b0);
-                if (k > 0) mma(a1, b1);            // deferred: k-slice 3 of the previous step (fragments already in registers)
+                if (k > 0) mma(a1, b1, std::integral_constant<int, 0>{});            // deferred: k-slice 3 of the previous step (fragments already in registers)
                 pieces(0, (NP + 3) / 4);
                 stamp(k, 3);
                 load_frags(st, 1, a1, b1);
                 pieces((NP + 3) / 4, (NP + 1) / 2);
-                mma(a0, b0);
+                mma(a0, b0, std::integral_constant<int, 0>{});
                 load_frags(st, 2, a0, b0);
                 pieces((NP + 1) / 2, (3 * NP + 3) / 4);
-                mma(a1, b1);
+                mma(a1, b1, std::integral_constant<int, 0>{});
                 load_frags(st, 3, a1, b1);
                 pieces((3 * NP + 3) / 4, NP);
-                mma(a0, b0);
+                mma(a0, b0, std::integral_constant<int, 0>{});
                 stamp(k, 4);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // k-slice 3 fragments are in registers before the stage is released
                 stamp(k, 5);
             }
-            if constexpr (BN != 384) mma(a1, b1);  // k-slice 3 of the tile's last step
+            if constexpr (BN != 384) mma(a1, b1, std::integral_constant<int, 0>{});  // k-slice 3 of the tile's last step
 #endif
         };
         if constexpr (swapped) kloop(std::true_type{}); else kloop(std::false_type{});
@@ -963,21 +1028,33 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     GemmParams pg = p;
     if ((epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
         pg.xcd_ngroups = 2;
-#define TLD_L256P(E)                                                                                  \
+#define TLD_L256P_(E, F8)                                                                             \
     do {                                                                                              \
-        constexpr int lds = (E) == EPI_UP_DWCONV && G::UPDW_LDS > G::LDS_BYTES ? G::UPDW_LDS                     \
+        constexpr int lds = (F8) ? G::LDS_BYTES + 4096                                                \
+                            : ((E) == EPI_UP_DWCONV && G::UPDW_LDS > G::LDS_BYTES ? G::UPDW_LDS       \
                             : ((E) == EPI_UP_DWCONV2 ? G::UPDW2_LDS                                   \
                             : ((E) == EPI_QKV_LN ? G::QKVLN_LDS                                        \
-                            : ((E) == EPI_BIAS_BF16 ? G::PLAINLN_LDS : G::LDS_BYTES)));               \
+                            : ((E) == EPI_BIAS_BF16 ? G::PLAINLN_LDS : G::LDS_BYTES))));              \
         static bool once = false;                                                                     \
         if (!once) {                                                                                  \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E>),                \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E, F8>),            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
             once = true;                                                                              \
         }                                                                                             \
-        hipLaunchKernelGGL((gemm256p_kernel<BN, E>), grid, block, lds, s, pg, nblocks);               \
+        hipLaunchKernelGGL((gemm256p_kernel<BN, E, F8>), grid, block, lds, s, pg, nblocks);           \
     } while (0)
-    if constexpr (BN == 192 || BN == 384) {
+#define TLD_L256P(E) TLD_L256P_(E, false)
+    if (p.f8) {             // MX-fp8 operands: 256- or 128-wide tiles, four epilogues
+        if constexpr (BN == 256 || BN == 128) {
+            switch (epilogue) {
+                case EPI_F32: TLD_L256P_(EPI_F32, true); break;
+                case EPI_QKV: TLD_L256P_(EPI_QKV, true); break;
+                case EPI_BIAS_BF16: TLD_L256P_(EPI_BIAS_BF16, true); break;
+                case EPI_BIAS_RESID: TLD_L256P_(EPI_BIAS_RESID, true); break;
+                default: break;
+            }
+        }
+    } else if constexpr (BN == 192 || BN == 384) {
         TLD_L256P(EPI_BIAS_RESID);
     } else {
         switch (epilogue) {
@@ -991,6 +1068,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
             default: break;
         }
     }
+#undef TLD_L256P_
 #undef TLD_L256P
 }
 
@@ -1033,7 +1111,8 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
 #else
     const GemmParams& p = p_in;
 #endif
-    const int bn = choose_bn(p.M, p.N, epilogue);
+    int bn = choose_bn(p.M, p.N, epilogue);
+    if (p.f8) bn = (p.N % 256 == 0) ? 256 : 128;            // the fp8 kernel is instantiated for these two widths
     // (A column-split QKV launch -- 8 tile-columns of 256 as 4 whole rounds + the 9th as 128-wide tiles -- was
     // measured: 109.8 + 27.8 us vs 134 us for the single 4.5-round launch; a one-round launch pays ~12 us of
     // ramp/drain, so the half-empty fifth round is the cheaper tail.)

@@ -55,6 +55,7 @@ class Denoiser:
         self._engine = None
         self._engine_batch = 0
         self._engine_device = None
+        self._gemm_dtype = 0              # 0: bf16 operands; 1: MX-fp8 QKV / MLP GEMMs (set_gemm_dtype)
         self.training = False
 
     # ---- nn.Module-like surface ------------------------------------------------------------------
@@ -142,6 +143,8 @@ class Denoiser:
         h = C.c_void_p()
         _lib.check(L.tld_engine_create(C.byref(cfg), C.byref(h)), "tld_engine_create")
         try:
+            if self._gemm_dtype:
+                _lib.check(L.tld_engine_set_gemm_dtype(h, self._gemm_dtype), "tld_engine_set_gemm_dtype")
             for k, t in self._state.items():
                 if t.dtype == torch.int64:
                     continue
@@ -155,6 +158,15 @@ class Denoiser:
             raise
         self._engine, self._engine_batch, self._engine_device = h, cap, dev
         return h
+
+    def set_gemm_dtype(self, name: str) -> "Denoiser":
+        """Operand type of the QKV / MLP GEMMs: ``"bf16"`` (default) or ``"fp8"`` (MX-fp8: e4m3 elements, E8M0 scale
+        per 32 K-elements, activations quantised on the fly; BASELINE config C4 -- not a mode of the reference)."""
+        code = {"bf16": 0, "fp8": 1}[name]
+        if code != self._gemm_dtype:
+            self._drop_engine()
+        self._gemm_dtype = code
+        return self
 
     def reserve(self, model_batch: int, device=None) -> "Denoiser":
         """Build the engine for up to ``model_batch`` samples per forward (CFG-doubled count)."""
