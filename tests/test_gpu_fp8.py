@@ -18,7 +18,7 @@ from test_gpu_parity import _dev, _t
 
 pytestmark = pytest.mark.gpu
 
-FP8_FWD_TOL = 8e-2        # forward rel-rms vs the fp32 reference with all QKV / MLP GEMMs in MX-fp8 (measured: see DESIGN.md)
+FP8_FWD_TOL = 6e-2        # forward rel-rms vs the fp32 reference with all QKV / MLP GEMMs in MX-fp8 (measured 2.5e-2 .. 4.6e-2: DESIGN.md 4.4)
 
 
 def _stream():
@@ -59,7 +59,8 @@ def test_mx8_gemm_equals_product_of_dequantised_operands(M, N, K):
     torch.cuda.synchronize()
     err = (c.cpu() - ref).abs().max().item()
     scale = ref.abs().max().item()
-    assert err <= 1e-5 * scale * np.sqrt(K / 128) + 1e-6, (err, scale)
+    # (the MFMA accumulates 64 scaled products per instruction in its own order: agreement is at fp32-rounding level)
+    assert err <= 5e-5 * scale * np.sqrt(K / 128) + 1e-6, (err, scale)
 
 
 def _fp8_engine(g):

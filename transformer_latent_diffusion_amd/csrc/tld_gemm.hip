@@ -236,12 +236,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 #pragma unroll
             for (int j = 0; j < G::TN; ++j) b[j] = read_frag(st + G::A_BYTES, wn * G::WCOLS + j * 32 + l31, kc);
         } else {
-            // lane (row l31, half hi) holds K-elements [64 ks + 32 hi, +32) of its row: logical 16-B chunks c, c + 1
-            const int c = ks * 4 + hi * 2;
+            // Operand layout of v_mfma_scale_f32_32x32x64_f8f6f4 (probed on gfx950, tools/ubench/mx_probe.hip): lane
+            // (row l31, half hi) holds K-elements 16 hi .. 16 hi + 15 in its lower four registers and 32 + 16 hi .. + 15 in
+            // its upper four; the scale byte of lane (r, 0) applies to k 0-31 of row r, that of lane (r, 1) to k 32-63.
+            // In 16-B chunks of the 64-element k-slice ks: chunks hi and 2 + hi.
+            const int c = ks * 4 + hi;
             auto rd = [&](const char* base, int row) {
                 const int sw = (row >> 1) & 7;
                 const u32x4 lo = *reinterpret_cast<const u32x4*>(base + row * 128 + ((c ^ sw) << 4));
-                const u32x4 hi4 = *reinterpret_cast<const u32x4*>(base + row * 128 + (((c + 1) ^ sw) << 4));
+                const u32x4 hi4 = *reinterpret_cast<const u32x4*>(base + row * 128 + (((c + 2) ^ sw) << 4));
                 return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
             };
 #pragma unroll
@@ -1044,7 +1047,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
         hipLaunchKernelGGL((gemm256p_kernel<BN, E, F8>), grid, block, lds, s, pg, nblocks);           \
     } while (0)
 #define TLD_L256P(E) TLD_L256P_(E, false)
-    if (p.f8) {             // MX-fp8 operands: 256- or 128-wide tiles, four epilogues
+    if (p.f8) {             // MX-fp8 operands: 256- or 128-wide tiles with four epilogues, 192-wide for the residual add
         if constexpr (BN == 256 || BN == 128) {
             switch (epilogue) {
                 case EPI_F32: TLD_L256P_(EPI_F32, true); break;
@@ -1053,6 +1056,8 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
                 case EPI_BIAS_RESID: TLD_L256P_(EPI_BIAS_RESID, true); break;
                 default: break;
             }
+        } else if constexpr (BN == 192) {
+            if (epilogue == EPI_BIAS_RESID) TLD_L256P_(EPI_BIAS_RESID, true);
         }
     } else if constexpr (BN == 192 || BN == 384) {
         TLD_L256P(EPI_BIAS_RESID);
@@ -1112,7 +1117,11 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
     const GemmParams& p = p_in;
 #endif
     int bn = choose_bn(p.M, p.N, epilogue);
-    if (p.f8) bn = (p.N % 256 == 0) ? 256 : 128;            // the fp8 kernel is instantiated for these two widths
+    if (p.f8) {             // the fp8 kernel is instantiated for 256 / 128 (all epilogues) and 192 (residual add: N = 768 in whole rounds)
+        const long ntm = (p.M + 255) / 256;
+        if (epilogue == EPI_BIAS_RESID && p.N % 192 == 0 && ((ntm * (p.N / 192)) % 256 == 0 || p.N % 256 != 0)) bn = 192;
+        else bn = (p.N % 256 == 0) ? 256 : 128;
+    }
     // (A column-split QKV launch -- 8 tile-columns of 256 as 4 whole rounds + the 9th as 128-wide tiles -- was
     // measured: 109.8 + 27.8 us vs 134 us for the single 4.5-round launch; a one-round launch pays ~12 us of
     // ramp/drain, so the half-empty fifth round is the cheaper tail.)
