@@ -71,6 +71,36 @@ def test_text_to_image_shell():
     assert np.array_equal(np.asarray(out4)[4:132, 4:132], np.asarray(out))
 
 
+def test_batched_text_to_image_front_edge():
+    """generate_images_from_texts / RequestBatcher: several prompts, one sampler call; each picture equals the
+    single-prompt call with the same prompt and seed (pixel-exact: samples never interact)."""
+    from PIL import Image
+    from transformer_latent_diffusion_amd import DenoiserConfig, DiffusionTransformer, LTDConfig, RequestBatcher
+
+    class FakeVAE:
+        def decode(self, z):
+            return (torch.tanh(z[:, :3]).repeat_interleave(8, dim=2).repeat_interleave(8, dim=3),)
+
+    def text_encoder(prompts):                       # deterministic per prompt, independent of the batch it arrives in
+        rows = [torch.randn(768, generator=torch.Generator().manual_seed(sum(map(ord, p)))) * 0.5 for p in prompts]
+        return torch.stack(rows).to(_dev())          # stays on the device
+
+    pipe = DiffusionTransformer(LTDConfig(denoiser_cfg=DenoiserConfig(n_channels=4)), vae=FakeVAE(), text_encoder=text_encoder,
+                                run_device=_dev())
+    prompts, seeds = ["a cute cat", "a red car", "tree"], [11, 5, 7]
+    imgs = pipe.generate_images_from_texts(prompts, class_guidance=6, seeds=seeds, n_iter=5)
+    assert len(imgs) == 3 and all(isinstance(im, Image.Image) and im.size == (128, 128) for im in imgs)
+    for p, s, im in zip(prompts, seeds, imgs):
+        single = pipe.generate_image_from_text(prompt=p, seed=s, n_iter=5)
+        assert np.array_equal(np.asarray(single), np.asarray(im)), p
+    rb = RequestBatcher(pipe, max_batch=8)
+    tickets = [rb.submit(p, 6, s, 5) for p, s in zip(prompts, seeds)] + [rb.submit("tree", 3, 7, 5)]
+    out = rb.flush()
+    assert all(np.array_equal(np.asarray(out[t]), np.asarray(im)) for t, im in zip(tickets[:3], imgs))
+    assert not np.array_equal(np.asarray(out[tickets[3]]), np.asarray(imgs[2]))            # other guidance, other picture
+    assert pipe.generate_images_from_texts([]) == []
+
+
 def test_c1_full_size_sampler_vs_reference_trajectory():
     """The bench workload itself (64 images, 35 steps, CFG 6: share-L0 fan-out, 384-wide down tiles, XCD grid -- all
     only active at this size): sample 0 carries the g5 trajectory inputs and must land on the reference's end latent,

@@ -145,3 +145,29 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"(from|import)\s+oracle\b|tld_oracle|libtld_oracle|oracle/", txt):
                     offenders.append(os.path.join(dp, f))
     assert not offenders, offenders
+
+
+def test_request_batcher_groups_by_sampler_scalars():
+    """Serving-side batching (tld/app.py:48-65 serves one request per call): requests sharing (class_guidance, n_iter)
+    become one sampler call each (split at max_batch); every request keeps its own prompt and seed."""
+    from transformer_latent_diffusion_amd import RequestBatcher
+
+    class FakePipe:
+        def __init__(self):
+            self.calls = []
+
+        def generate_images_from_texts(self, prompts, class_guidance, seeds, n_iter):
+            self.calls.append((list(prompts), class_guidance, list(seeds), n_iter))
+            return [f"img:{p}:{s}" for p, s in zip(prompts, seeds)]
+
+    pipe = FakePipe()
+    rb = RequestBatcher(pipe, max_batch=2)
+    t = [rb.submit("a", 6, 1, 15), rb.submit("b", 3, 2, 15), rb.submit("c", 6, 3, 15), rb.submit("d", 6, 4, 15),
+         rb.submit("e", 6, 5, 30)]
+    assert rb.pending() == 5
+    plan = rb.plan()
+    assert [(g, n, [p for _, p, _ in r]) for g, n, r in plan] == [(6.0, 15, ["a", "c"]), (6.0, 15, ["d"]), (3.0, 15, ["b"]),
+                                                                   (6.0, 30, ["e"])]
+    out = rb.flush()
+    assert out == {t[0]: "img:a:1", t[1]: "img:b:2", t[2]: "img:c:3", t[3]: "img:d:4", t[4]: "img:e:5"}
+    assert rb.pending() == 0 and len(pipe.calls) == 4 and rb.flush() == {}

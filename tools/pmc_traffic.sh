@@ -1,14 +1,16 @@
 #!/bin/bash
 # HBM-side traffic of every kernel of one bench step, from PMC counters (separate passes for FETCH_SIZE and
 # WRITE_SIZE as the microarch guide prescribes; counters only -- no tracing flags on these runs).
-# usage (on the GPU box, from the repo root): tools/pmc_traffic.sh gpurun_out/pmc_traffic
+# usage (on the GPU box, from the repo root): tools/pmc_traffic.sh gpurun_out/pmc_traffic [extra bench.py flags]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+EXTRA_FLAGS="${@:2}"
+[ -z "$EXTRA_FLAGS" ] && EXTRA_FLAGS="--images-per-gpu 64"
 case $1 in /*) OUT=$1;; *) OUT=$R/$1;; esac
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for CNT in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $CNT --output-format csv -d $OUT/$CNT -o p -- \
-      python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile --images-per-gpu 64 > $OUT/$CNT.log 2>&1
+      python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile $EXTRA_FLAGS > $OUT/$CNT.log 2>&1
 done
 python - <<PY
 import csv, glob, json, collections

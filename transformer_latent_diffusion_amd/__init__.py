@@ -2,7 +2,7 @@
 ``Denoiser`` / ``DiffusionGenerator`` / ``DiffusionTransformer`` hot path)."""
 from .configs import ClipConfig, DenoiserConfig, DenoiserLoad, LTDConfig, VaeConfig, config_100m  # noqa: F401
 from .denoiser import Denoiser  # noqa: F401
-from .diffusion import DiffusionGenerator, DiffusionTransformer  # noqa: F401
+from .diffusion import DiffusionGenerator, DiffusionTransformer, RequestBatcher  # noqa: F401
 
 __all__ = ["ClipConfig", "DenoiserConfig", "DenoiserLoad", "LTDConfig", "VaeConfig", "config_100m", "Denoiser",
-           "DiffusionGenerator", "DiffusionTransformer"]
+           "DiffusionGenerator", "DiffusionTransformer", "RequestBatcher"]

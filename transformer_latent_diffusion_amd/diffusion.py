@@ -163,6 +163,38 @@ class DiffusionTransformer:
         tokens = clip.tokenize(prompts, truncate=True).to(self.device)
         return self.clip_model.encode_text(tokens).cpu()
 
+    @torch.no_grad()
+    def generate_images_from_texts(self, prompts, class_guidance=6, seeds=11, n_iter=15):
+        """Batched front edge (the reference serves one prompt per call, tld/app.py:48-65):
+        one text-encoder call for all prompts, labels stay on the device, ONE sampler call (sample-sharded over the
+        ranks of the default process group when torch.distributed is initialised), one VAE decode; returns one PIL image
+        per prompt.  ``seeds``: an int (request i uses seeds + i) or one int per prompt.  Request i's picture is exactly
+        what ``generate_image_from_text(prompts[i], seed=seeds[i])`` returns: samples never interact."""
+        from .sharded import sharded_sample
+        prompts = list(prompts)
+        n = len(prompts)
+        if n == 0:
+            return []
+        seed_list = [int(seeds) + i for i in range(n)] if isinstance(seeds, int) else [int(v) for v in seeds]
+        if len(seed_list) != n:
+            raise ValueError(f"{len(seed_list)} seeds for {n} prompts")
+        if self._text_encoder is not None:
+            labels = self._text_encoder(prompts)
+        else:
+            import clip
+            labels = self.clip_model.encode_text(clip.tokenize(prompts, truncate=True).to(self.device))
+        labels = labels.to(self.device, torch.float32)
+        gen, size = self.diffuser, self.diffuser.model.image_size
+        x_T = torch.cat([gen.initialize_image(None, 1, size, s) for s in seed_list])     # each request's own noise
+
+        def one(xs, ls):
+            return gen.generate_latents(ls, n_iter=n_iter, num_imgs=xs.shape[0], class_guidance=class_guidance, img_size=size,
+                                        sharp_f=0, bright_f=0, exponent=1, seeds=xs)
+
+        latents = sharded_sample(one, x_T, labels)
+        out = gen.vae.decode((latents * 8).to(gen.model_dtype))[0].cpu()                # scale_factor 8 (diffusion.py:180)
+        return [to_pil(((out[i] + 1) / 2).float().clip(0, 1)) for i in range(n)]
+
     def generate_image_from_text(self, prompt: str, class_guidance=6, seed=11, num_imgs=1, img_size=32, n_iter=15):
         nrow = int(np.sqrt(num_imgs))
         labels = self.encode_text([prompt] * num_imgs)
@@ -172,3 +204,49 @@ class DiffusionTransformer:
             class_guidance=class_guidance, seed=seed, n_iter=n_iter, exponent=1, scale_factor=8, sharp_f=0,
             bright_f=0)
         return to_pil(make_image_grid((out + 1) / 2, nrow=nrow, padding=4).float().clip(0, 1))
+
+
+
+class RequestBatcher:
+    """Groups text-to-image requests into batched sampler calls (serving-side batching; the reference's FastAPI
+    handler runs the blocking pipeline once per request, tld/app.py:48-65).
+
+    ``class_guidance`` and ``n_iter`` are per-call scalars of the sampler, so requests are grouped by that pair;
+    inside a group every request keeps its own prompt and seed.  Synchronous by design: ``submit`` queues,
+    ``flush`` runs the queued groups (largest first, at most ``max_batch`` requests per sampler call) and returns
+    ``{ticket: PIL.Image}``."""
+
+    def __init__(self, pipeline: "DiffusionTransformer", max_batch: int = 64):
+        self.pipeline = pipeline
+        self.max_batch = int(max_batch)
+        self._queue = []
+        self._next = 0
+
+    def submit(self, prompt: str, class_guidance: float = 6, seed: int = 11, n_iter: int = 15) -> int:
+        ticket = self._next
+        self._next += 1
+        self._queue.append((ticket, str(prompt), float(class_guidance), int(seed), int(n_iter)))
+        return ticket
+
+    def pending(self) -> int:
+        return len(self._queue)
+
+    def plan(self):
+        """[(class_guidance, n_iter, [(ticket, prompt, seed), ...]), ...] -- the sampler calls ``flush`` will make."""
+        groups = {}
+        for t, p, g, s, n in self._queue:
+            groups.setdefault((g, n), []).append((t, p, s))
+        calls = []
+        for (g, n), reqs in sorted(groups.items(), key=lambda kv: -len(kv[1])):
+            for i in range(0, len(reqs), self.max_batch):
+                calls.append((g, n, reqs[i:i + self.max_batch]))
+        return calls
+
+    def flush(self):
+        out = {}
+        for g, n, reqs in self.plan():
+            imgs = self.pipeline.generate_images_from_texts([p for _, p, _ in reqs], class_guidance=g,
+                                                            seeds=[s for _, _, s in reqs], n_iter=n)
+            out.update({t: im for (t, _, _), im in zip(reqs, imgs)})
+        self._queue = []
+        return out
