@@ -101,3 +101,22 @@ def test_fp8_c4_sampler_shape_runs():
     one = gen.generate_latents(labels[:1], num_imgs=1, seeds=seeds[:1], **kw)
     assert torch.isfinite(two).all() and torch.equal(two[0], one[0])
     assert torch.equal(two, gen.generate_latents(labels, num_imgs=2, seeds=seeds, **kw))
+
+
+@pytest.mark.parametrize("name", ["g5_100m.npz", "g7_100m_512px.npz"])
+def test_fp8_quantising_producers_equal_separate_passes(name):
+    """The LayerNorm / cross-attention / tiled depthwise kernels write the MX-fp8 operands themselves; with
+    TLD_FP8_FUSED=0 the engine quantises their bf16 outputs in separate passes instead.  Same bytes, same result."""
+    import os
+    g = load_golden(name)
+    outs = []
+    for fused in ("1", "0"):
+        old = os.environ.get("TLD_FP8_FUSED")
+        os.environ["TLD_FP8_FUSED"] = fused
+        try:
+            cfg, m = _fp8_engine(g)
+            m.reserve(8)                                 # the switch is read when the engine is created
+        finally:
+            os.environ.pop("TLD_FP8_FUSED", None) if old is None else os.environ.__setitem__("TLD_FP8_FUSED", old)
+        outs.append(m(_t(g["x"]), _t(g["sigma"]), _t(g["label"])).cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])

@@ -151,6 +151,28 @@ __device__ __forceinline__ void rs_store4(resid_t* p, float4 v) {
 #endif
 }
 
+// MX-fp8 output of a row producer (fp8 GEMM mode): the four values of this lane and those of the 7 other lanes of its aligned
+// 8-lane group form one 32-element block (the row kernels' 4-features-per-lane layout and the depthwise kernels' channel quads
+// both have that shape).  Returns the packed e4m3 dword; *e8 is the block's E8M0 byte (same in all 8 lanes).  Same arithmetic as
+// quant_mx8_kernel (tld_quant.hip): X = 2^(floor(log2 amax) - 8), saturating conversion.
+__device__ __forceinline__ unsigned mx8_pack4(float v0, float v1, float v2, float v3, int* e8_out) {
+    float amax = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+    amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0xB1, 0xf, 0xf, true)));    // lane ^ 1
+    amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0x4E, 0xf, 0xf, true)));    // lane ^ 2
+    amax = fmaxf(amax, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amax), 0x141, 0xf, 0xf, true)));   // 8-lane mirror
+    const int e_amax = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    const int e8 = e_amax > 8 ? e_amax - 8 : 0;
+    const float inv = __uint_as_float((unsigned)(254 - e8) << 23);
+    auto cl = [&](float v) { return fminf(fmaxf(v * inv, -448.f), 448.f); };
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v0), cl(v1), w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(v2), cl(v3), w, true);
+    *e8_out = e8;
+    return (unsigned)w;
+}
+// scale byte address of (row, first K-element k of a 32-block) in the GEMM's [K/128][rows][4] layout
+__device__ __forceinline__ size_t mx8_scale_index(int k, size_t row, size_t rows) { return ((size_t)(k >> 7) * rows + row) * 4 + ((k >> 5) & 3); }
+
 // value the residual stream will hold after a store (what a later LayerNorm of the stored row sees)
 __device__ __forceinline__ float rs_round(float v) { return (float)(resid_t)v; }
 
@@ -242,8 +264,11 @@ void launch_attention(const bf16* qk, const bf16* vt, bf16* att, int batch, int 
 
 // depthwise 3x3 (zero pad) + bias + exact GELU on channels-last [B, g, g, C] bf16
 // (w9c_half / bias_half: the same tables times 0.5, used by the spatially tiled kernel's half-argument GELU)
+// out8 / scale8 non-null (spatially tiled kernel only): the result goes out as e4m3 [M, C] + E8M0 scales [C/128][M][4]
+// (fp8 GEMM mode) instead of bf16
 void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c /*[9][C]*/, const float* bias, const float* w9c_half,
-                        const float* bias_half, int batch, int grid, int channels, hipStream_t s);
+                        const float* bias_half, int batch, int grid, int channels, hipStream_t s, uint8_t* out8 = nullptr,
+                        uint8_t* scale8 = nullptr);
 
 struct EmbedParams {
     const float* x;               // [B,C,S,S] fp32
@@ -264,6 +289,10 @@ void launch_embed(const EmbedParams& p, hipStream_t s);
 // LayerNorm rows: x [M,d] -> bf16 normalized-affine [M,d]
 void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf16* out, int M, int d,
                            hipStream_t s);
+// the same rows straight into the fp8 GEMM's operand format: e4m3 [M,d] + E8M0 scales [d/128][M][4]  (d % 256 == 0)
+bool layernorm_mx8_supported(int d);
+void launch_layernorm_mx8(const resid_t* x, const float* g, const float* b, uint8_t* out8, uint8_t* scale8, int M, int d,
+                          hipStream_t s);
 
 // Fused row kernel of one decoder block's middle:
 //   x += att (self-attention residual);  cross-attention to the 2 conditioning tokens computed from
@@ -283,6 +312,8 @@ struct CrossRowParams {
     bf16* xn3;                    // [M,d]  LN3(x) for the up-projection (null when ln3_stats is used instead)
     float2* ln3_stats;            // optional [M]: (mean, rstd) of the ROUNDED new residual row -- LN3 is then applied
                                   // inside the fused up-projection's epilogue and xn3 is never written
+    uint8_t* xn3_f8;              // optional (fp8 GEMM mode, 4-features-per-lane kernel): LN3(x) as e4m3 [M,d] instead of xn3 ...
+    uint8_t* xn3_s8;              //   ... and its E8M0 block scales [d/128][M][4]
     float* sa_out;                // optional debug dump of x + att  [M,d]
     int batch, ntok, d, heads;
 };

@@ -91,6 +91,7 @@ struct tld_engine {
     bool fuse_dwconv = true;            // TLD_FUSE_DWCONV=0 selects the two-kernel path (A/B testing)
     bool updw_v2 = true;                // TLD_UPDW_V2=0: first form of the fused depthwise epilogue (fp32 taps, A/B testing)
     bool fp8 = false;                   // QKV / MLP GEMMs on MX-fp8 operands (BASELINE config C4); set before finalize
+    bool fp8_fused = true;              // TLD_FP8_FUSED=0: separate quantisation passes instead of quantising producers (A/B testing)
     uint8_t *a8 = nullptr, *as8 = nullptr;   // fp8 mode: quantised A operand [M, hid] and its block scales [hid/128][M][4]
     std::map<std::string, HostTensor> host;
     std::vector<void*> allocs;
@@ -286,17 +287,19 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
         const Layer& Ly = e->layers[l];
         const bool half = share_l0 && l == 0;
         const int bl = half ? b0 : batch, Ml = bl * e->ntok;
+        const bool fuse8 = e->fp8 && e->fp8_fused;      // fp8 mode: producers write the MX-fp8 operand themselves
         if (!fold1) {   // xn = LN1(x)
             ProfScope ps(e, KC_LN, s);
-            launch_layernorm_bf16(half ? xe : e->x, Ly.n1_w, Ly.n1_b, e->xn, Ml, d, s);
+            if (fuse8 && layernorm_mx8_supported(d)) launch_layernorm_mx8(half ? xe : e->x, Ly.n1_w, Ly.n1_b, e->a8, e->as8, Ml, d, s);
+            else launch_layernorm_bf16(half ? xe : e->x, Ly.n1_w, Ly.n1_b, e->xn, Ml, d, s);
         }
         {   // q|k, v^T = LN1(x) Wqkv^T
             ProfScope ps(e, KC_GEMM_QKV, s);
             GemmParams g{};
             g.A = e->xn; g.lda = d; g.W = Ly.qkv_w; g.ldw = d; g.M = Ml; g.N = 3 * d; g.K = d;
             g.out_bf16 = e->qk; g.ldo = 2 * d; g.vt = e->vt; g.ntok = e->ntok; g.d = d;
-            if (e->fp8) {   // MX-fp8: quantise LN1(x) (one pass over [M, d]), then the e4m3 GEMM
-                launch_quant_mx8(e->xn, e->a8, e->as8, Ml, d, s);
+            if (e->fp8) {   // MX-fp8: quantise LN1(x) (one pass over [M, d]; fused into the LayerNorm kernel when possible), then the e4m3 GEMM
+                if (!(fuse8 && layernorm_mx8_supported(d))) launch_quant_mx8(e->xn, e->a8, e->as8, Ml, d, s);
                 g.f8 = 1; g.A = reinterpret_cast<const bf16*>(e->a8); g.W = reinterpret_cast<const bf16*>(Ly.qkv_w8);
                 g.a_scale = e->as8; g.w_scale = Ly.qkv_s8;
             }
@@ -334,6 +337,8 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             cp.ln2_w = Ly.n2_w; cp.ln2_b = Ly.n2_b; cp.ln3_w = Ly.n3_w; cp.ln3_b = Ly.n3_b;
             cp.xn3 = fold3 ? nullptr : e->xn; cp.ln3_stats = fold3 ? e->row_stats : nullptr; cp.batch = batch; cp.ntok = e->ntok; cp.d = d; cp.heads = e->H;
             cp.sa_out = (l == 0 && e->debug) ? e->stages["blk0_sa"] : nullptr;
+            const bool cross8 = fuse8 && cross_row_supports_ln3_stats(d);      // (= the 4-features-per-lane kernel is in use)
+            if (cross8) { cp.xn3_f8 = e->a8; cp.xn3_s8 = e->as8; }
             launch_cross_row(cp, s);
         }
         if (l == 0) if (int rc = capture(e, "blk0_ca", e->x, (size_t)M * d, s)) return rc;
@@ -356,7 +361,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
                 g.A = e->xn; g.lda = d; g.W = Ly.up_w; g.ldw = d; g.M = M; g.N = e->hid; g.K = d;
                 g.out_bf16 = e->hid1; g.ldo = e->hid; g.bias = Ly.up_b;
                 if (e->fp8) {
-                    launch_quant_mx8(e->xn, e->a8, e->as8, M, d, s);
+                    if (!(fuse8 && cross_row_supports_ln3_stats(d))) launch_quant_mx8(e->xn, e->a8, e->as8, M, d, s);
                     g.f8 = 1; g.A = reinterpret_cast<const bf16*>(e->a8); g.W = reinterpret_cast<const bf16*>(Ly.up_w8);
                     g.a_scale = e->as8; g.w_scale = Ly.up_s8;
                 }
@@ -369,7 +374,9 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             }
             {
                 ProfScope ps(e, KC_DWCONV, s);
-                launch_dwconv_gelu(e->hid1, e->hid2, Ly.dw_w9c, Ly.dw_b, Ly.dw_w9c_half, Ly.dw_b_half, batch, e->grid, e->hid, s);
+                const bool dw8 = fuse8 && e->grid > 16;       // the tiled kernel writes the fp8 operand of the down projection itself
+                launch_dwconv_gelu(e->hid1, e->hid2, Ly.dw_w9c, Ly.dw_b, Ly.dw_w9c_half, Ly.dw_b_half, batch, e->grid, e->hid, s,
+                                   dw8 ? e->a8 : nullptr, dw8 ? e->as8 : nullptr);
             }
         }
         {   // x += hid2 Wdown^T + b
@@ -379,7 +386,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             g.bias = Ly.down_b; g.resid = e->x; g.ldr = d;
             g.stats_out = (fold1 && l + 1 < e->L) ? e->ln_stats : nullptr;
             if (e->fp8) {
-                launch_quant_mx8(e->hid2, e->a8, e->as8, M, e->hid, s);
+                if (!(fuse8 && e->grid > 16)) launch_quant_mx8(e->hid2, e->a8, e->as8, M, e->hid, s);
                 g.f8 = 1; g.A = reinterpret_cast<const bf16*>(e->a8); g.W = reinterpret_cast<const bf16*>(Ly.down_w8);
                 g.a_scale = e->as8; g.w_scale = Ly.down_s8;
             }
@@ -457,6 +464,7 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     if (const char* fd = getenv("TLD_FUSE_DWCONV")) e->fuse_dwconv = atoi(fd) != 0;
     if (const char* sl = getenv("TLD_SHARE_L0")) e->share_l0 = atoi(sl) != 0;
     if (const char* v2 = getenv("TLD_UPDW_V2")) e->updw_v2 = atoi(v2) != 0;
+    if (const char* f8 = getenv("TLD_FP8_FUSED")) e->fp8_fused = atoi(f8) != 0;
     if (const char* fl = getenv("TLD_FOLD_LN3")) e->fold_ln3 = atoi(fl) != 0;
     if (const char* fl = getenv("TLD_FOLD_LN1")) e->fold_ln1 = atoi(fl) != 0;
 #ifndef TLD_RESID_BF16

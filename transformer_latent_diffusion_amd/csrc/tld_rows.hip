@@ -208,6 +208,45 @@ __global__ __launch_bounds__(256) void layernorm_bf16_q4_kernel(const resid_t* _
     }
 }
 
+// fp8 GEMM mode: the same LayerNorm rows written straight in the MX-fp8 operand format (no bf16 copy, no separate
+// quantisation pass).  A 32-feature block is 8 adjacent lanes of one 256-feature chunk.
+template <int NQ>
+__global__ __launch_bounds__(256) void layernorm_mx8_kernel(const resid_t* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ b, uint8_t* __restrict__ out8,
+                                                            uint8_t* __restrict__ scale8, int M, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float4 v[NQ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        v[j] = rs_load4(x + (size_t)row * d + j * 256 + 4 * lane);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+        q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int n = j * 256 + 4 * lane;
+        const float4 gg = *reinterpret_cast<const float4*>(g + n);
+        const float4 bb = *reinterpret_cast<const float4*>(b + n);
+        // (rounded through bf16 first: the operand the bf16 path would have produced is what gets quantised)
+        const float y0 = (float)(bf16)(v[j].x * rstd * gg.x + bb.x), y1 = (float)(bf16)(v[j].y * rstd * gg.y + bb.y);
+        const float y2 = (float)(bf16)(v[j].z * rstd * gg.z + bb.z), y3 = (float)(bf16)(v[j].w * rstd * gg.w + bb.w);
+        int e8;
+        const unsigned w = mx8_pack4(y0, y1, y2, y3, &e8);
+        *reinterpret_cast<unsigned*>(out8 + (size_t)row * d + n) = w;
+        if ((lane & 7) == 0) scale8[mx8_scale_index(n, (size_t)row, (size_t)M)] = (uint8_t)e8;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Cross-attention has only two keys per sample (the noise token and the label token), so
 //   softmax([q.k_n, q.k_l] / 8) = [1 - s, s],  s = sigmoid((q.k_l - q.k_n) / 8),
@@ -579,7 +618,14 @@ __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, 
                 const f32x4 r = __builtin_elementwise_fma(v[u][j] * rstd3[u], gg, bb);
                 bf16x4 o;
                 o[0] = (bf16)r[0]; o[1] = (bf16)r[1]; o[2] = (bf16)r[2]; o[3] = (bf16)r[3];
-                *reinterpret_cast<bf16x4*>(p.xn3 + (row + u) * d + n) = o;
+                if (p.xn3_f8) {      // fp8 GEMM mode: MX-quantise the bf16-rounded row in place of the bf16 store
+                    int e8;
+                    const unsigned w = mx8_pack4((float)o[0], (float)o[1], (float)o[2], (float)o[3], &e8);
+                    *reinterpret_cast<unsigned*>(p.xn3_f8 + (row + u) * d + n) = w;
+                    if ((lane & 7) == 0) p.xn3_s8[mx8_scale_index(n, row + u, (size_t)p.batch * p.ntok)] = (uint8_t)e8;
+                } else {
+                    *reinterpret_cast<bf16x4*>(p.xn3 + (row + u) * d + n) = o;
+                }
             }
         }
     }
@@ -767,10 +813,12 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(const bf16* __restrict
 // one load per iteration and the kernel ran at 2.7 TB/s).  Halo tokens outside the image are DMA'd from a clamped
 // (valid) address and never contribute: rows above / below the image meet zeroed copies of the top / bottom taps,
 // columns left / right of it are replaced by zero registers -- no zero fill, no predicated code in the window loop.
+template <bool F8OUT>
 __global__ __launch_bounds__(256) void dwconv_gelu_tiled_kernel(const bf16* __restrict__ in, bf16* __restrict__ out,
                                                                 const float* __restrict__ w9c,
                                                                 const float* __restrict__ bias, int batch,
-                                                                int g, int C) {
+                                                                int g, int C, uint8_t* __restrict__ out8,
+                                                                uint8_t* __restrict__ scale8) {
     constexpr int T = 16, TP = T + 2;
     constexpr int PIECES = (TP * TP + 7) / 8;              // 1-KiB DMA pieces (8 tokens x 128 B)
     __shared__ __attribute__((aligned(16))) char tile[PIECES * 1024];
@@ -847,7 +895,17 @@ __global__ __launch_bounds__(256) void dwconv_gelu_tiled_kernel(const bf16* __re
         a[0] = gelu_erf_fast2_half(a[0]); a[1] = gelu_erf_fast2_half(a[1]);
         bf16x4 o;
         o[0] = (bf16)a[0][0]; o[1] = (bf16)a[0][1]; o[2] = (bf16)a[1][0]; o[3] = (bf16)a[1][1];
-        if (lj < ncols) *reinterpret_cast<bf16x4*>(dst + (size_t)lj * C) = o;
+        if constexpr (F8OUT) {      // fp8 GEMM mode: MX-quantise the bf16-rounded quad (8 adjacent channel quads = one 32-block)
+            int e8;
+            const unsigned w = mx8_pack4((float)o[0], (float)o[1], (float)o[2], (float)o[3], &e8);
+            const size_t row = (size_t)b * g * g + (size_t)gi * g + (size_t)tx * T + lj;
+            if (lj < ncols) {
+                *reinterpret_cast<unsigned*>(out8 + row * C + c0) = w;
+                if ((cq & 7) == 0) scale8[mx8_scale_index(c0, row, (size_t)batch * g * g)] = (uint8_t)e8;
+            }
+        } else {
+            if (lj < ncols) *reinterpret_cast<bf16x4*>(dst + (size_t)lj * C) = o;
+        }
     };
     auto zero = [&](f32x2 (&c)[3][2]) {
 #pragma unroll
@@ -898,6 +956,17 @@ void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf1
     TLD_DISPATCH_NJ(d / 128, hipLaunchKernelGGL(layernorm_bf16_kernel<NJ>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d));
 }
 
+bool layernorm_mx8_supported(int d) { return d == 256 || d == 512 || d == 768 || d == 1024; }
+
+void launch_layernorm_mx8(const resid_t* x, const float* g, const float* b, uint8_t* out8, uint8_t* scale8, int M, int d,
+                          hipStream_t s) {
+    const dim3 gr((M + 3) / 4), bl(256);
+    if (d == 768) hipLaunchKernelGGL(layernorm_mx8_kernel<3>, gr, bl, 0, s, x, g, b, out8, scale8, M, d);
+    else if (d == 512) hipLaunchKernelGGL(layernorm_mx8_kernel<2>, gr, bl, 0, s, x, g, b, out8, scale8, M, d);
+    else if (d == 256) hipLaunchKernelGGL(layernorm_mx8_kernel<1>, gr, bl, 0, s, x, g, b, out8, scale8, M, d);
+    else if (d == 1024) hipLaunchKernelGGL(layernorm_mx8_kernel<4>, gr, bl, 0, s, x, g, b, out8, scale8, M, d);
+}
+
 // the LN3-statistics output (CrossRowParams::ln3_stats) exists in the 4-features-per-lane kernel only
 bool cross_row_supports_ln3_stats(int d) {
     static const bool q4 = !(getenv("TLD_CROSS_Q4") && atoi(getenv("TLD_CROSS_Q4")) == 0);
@@ -942,11 +1011,15 @@ void launch_update(const UpdateParams& p, hipStream_t s) {
 }
 
 void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c, const float* bias, const float* w9c_half,
-                        const float* bias_half, int batch, int grid, int channels, hipStream_t s) {
+                        const float* bias_half, int batch, int grid, int channels, hipStream_t s, uint8_t* out8,
+                        uint8_t* scale8) {
     if (grid > 16) {        // spatially tiled variant (halo in LDS); takes the halved tables
         const int tiles = (grid + 15) / 16;
-        hipLaunchKernelGGL(dwconv_gelu_tiled_kernel, dim3((unsigned)(batch * tiles * tiles * (channels / DW_CB))),
-                           dim3(256), 0, s, in, out, w9c_half, bias_half, batch, grid, channels);
+        const dim3 gr((unsigned)(batch * tiles * tiles * (channels / DW_CB)));
+        if (out8) hipLaunchKernelGGL(dwconv_gelu_tiled_kernel<true>, gr, dim3(256), 0, s, in, out, w9c_half, bias_half, batch, grid,
+                                     channels, out8, scale8);
+        else hipLaunchKernelGGL(dwconv_gelu_tiled_kernel<false>, gr, dim3(256), 0, s, in, out, w9c_half, bias_half, batch, grid,
+                                channels, out8, scale8);
         return;
     }
     const int lds = grid * grid * 128;
