@@ -235,6 +235,41 @@ def test_two_ranks_on_one_gpu_match_single_process(total, tmp_path):
     assert got.shape == ref.shape and np.array_equal(got, ref)
 
 
+_RCCL_SCRIPT = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r})
+from dataclasses import asdict
+from transformer_latent_diffusion_amd import Denoiser, DenoiserConfig, DiffusionGenerator
+from transformer_latent_diffusion_amd.sharded import generate_latents_sharded
+from transformer_latent_diffusion_amd.weights import synth_state_dict
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # RCCL communicator on this GPU
+cfg = DenoiserConfig(image_size=32, n_channels=4)
+m = Denoiser(**asdict(cfg)).to(dev)
+m.load_state_dict({{k: torch.from_numpy(np.array(v)) for k, v in synth_state_dict(cfg, 1).items()}})
+gen = DiffusionGenerator(m, None, dev, torch.float32)
+labels = torch.randn(4, 768, generator=torch.Generator().manual_seed(5)) * 0.5
+kw = dict(n_iter=6, num_imgs=4, class_guidance=4.0, seed=3, img_size=32, sharp_f=0.0, bright_f=0.0)
+out = generate_latents_sharded(gen, labels, **kw)                           # one all_gather_into_tensor on device memory
+ref = gen.generate_latents(labels, **kw)
+assert out.is_cuda and torch.equal(out, ref)
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_single_rank_all_gather(tmp_path):
+    """The backend the multi-GPU run uses ("nccl" = RCCL) with a one-rank communicator on this GPU: process-group
+    creation, the device-memory all_gather_into_tensor of sharded.py and teardown all execute (multi-rank RCCL needs more
+    GPUs than this box has; the 2-rank logic is covered by the gloo tests)."""
+    script = str(tmp_path / "rccl.py")
+    open(script, "w").write(_RCCL_SCRIPT.format(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 500))
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_bench_self_spawns_ranks():
     """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run (here: both ranks on
     the one GPU, gloo) and prints one JSON line for the 2-rank job."""

@@ -34,12 +34,17 @@ constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;   // (1/sqrt(64)
 template <int KT, int NW>   // 32-key tiles per chunk; NW waves (32 query rows each) per workgroup
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ qk,
                                                        const bf16* __restrict__ vt,
-                                                       bf16* __restrict__ att, int ntok, int d) {
+                                                       bf16* __restrict__ att, int ntok, int d, int nbuf) {
     constexpr int KC = KT * 32;                 // keys per chunk
     constexpr int VSTRIDE = KC * 2 + 8;         // bytes per V^T row in LDS (padded)
+    constexpr int KBYTES = KC * 128, VBYTES = 64 * VSTRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ks = smem;                            // KC * 128 bytes
-    char* Vs = smem + KC * 128;                 // 64 * VSTRIDE bytes
+    // nbuf = 2 (more than one chunk): K / V^T chunks are double-buffered -- the K chunk of step c+1 travels by DMA and the
+    // V^T chunk through registers while step c computes.  The kernel holds ~210 VGPRs (128 of them scores), i.e. ONE
+    // workgroup per CU, so with a single buffer every chunk's staging latency was exposed (two barriers and ~1.5 us of
+    // waiting per 256 keys).  Layout: [K0 | K1 | V0 | V1].
+    char* Kbase = smem;
+    char* Vbase = smem + nbuf * KBYTES;
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -66,37 +71,40 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
     float m_run = -INFINITY, l_run = 0.f;
 
     const int nchunks = ntok / KC;
+    constexpr int KP = KC / 8 / NW;              // 8-row K DMA pieces per wave
+    constexpr int PIECES = 64 * (KC / 8);
+    constexpr int PER_THREAD = PIECES / (NW * 64);
+    // K chunk: KC rows x 128 B, source-side XOR swizzle as in the GEMM tiles
+    auto stage_k = [&](int ch, char* Ks) {
+        const bf16* kbase = qk + (row_base + (size_t)ch * KC) * twod + d + h * 64;
+#pragma unroll
+        for (int it = 0; it < KP; ++it) {
+            const int r = (wid * KP + it) * 8 + (lane >> 3);
+            const int clog = (lane & 7) ^ ((r >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (size_t)r * twod + clog * 8), (lptr_t)(Ks + (wid * KP + it) * 1024), 16, 0, 0);
+        }
+    };
+    u32x4 vreg[PER_THREAD];
+    auto load_v = [&](int ch) {
+        const bf16* vbase = vt + ((size_t)b * d + h * 64) * ntok + (size_t)ch * KC;
+#pragma unroll
+        for (int it = 0; it < PER_THREAD; ++it) {
+            const int pidx = it * (NW * 64) + threadIdx.x;
+            const int c = pidx / (KC / 8), kc8 = pidx % (KC / 8);
+            vreg[it] = *reinterpret_cast<const u32x4*>(vbase + (size_t)c * ntok + kc8 * 8);
+        }
+    };
+    stage_k(0, Kbase);
+    load_v(0);
     for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch > 0) __syncthreads();            // everyone finished reading the previous chunk
-        // ---- stage K chunk: KC rows x 128 B, 8 rows per DMA piece, pieces split over waves
-        {
-            const bf16* kbase = qk + (row_base + (size_t)ch * KC) * twod + d + h * 64;
-            constexpr int KP = KC / 8 / NW;              // 8-row DMA pieces per wave
-#pragma unroll
-            for (int it = 0; it < KP; ++it) {
-                const int r = (wid * KP + it) * 8 + (lane >> 3);
-                const int cphys = lane & 7;
-                const int clog = cphys ^ ((r >> 1) & 7);
-                const bf16* src = kbase + (size_t)r * twod + clog * 8;
-                char* dst = Ks + (wid * KP + it) * 1024;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-            }
-        }
-        // K must be complete before S = K Q^T; the V^T chunk is only needed for the second MFMA, so its global
-        // loads are issued now and their latency hides behind the 32 score MFMAs and the softmax VALU work.
+        const int cur = nbuf == 2 ? (ch & 1) : 0;
+        char* Ks = Kbase + cur * KBYTES;
+        char* Vs = Vbase + cur * VBYTES;
+        // K chunk ch landed (own pieces: vmcnt; everybody's: barrier).  The barrier also says: every wave is past the PV
+        // MFMAs of chunk ch-1, so the OTHER K buffer (read by chunk ch-1's scores) may be overwritten now.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        constexpr int PIECES = 64 * (KC / 8);
-        constexpr int PER_THREAD = PIECES / (NW * 64);
-        u32x4 vreg[PER_THREAD];
-        {
-            const bf16* vbase = vt + ((size_t)b * d + h * 64) * ntok + (size_t)ch * KC;
-#pragma unroll
-            for (int it = 0; it < PER_THREAD; ++it) {
-                const int pidx = it * (NW * 64) + threadIdx.x;
-                const int c = pidx / (KC / 8), kc8 = pidx % (KC / 8);
-                vreg[it] = *reinterpret_cast<const u32x4*>(vbase + (size_t)c * ntok + kc8 * 8);
-            }
-        }
+        if (nbuf == 2 && ch + 1 < nchunks) stage_k(ch + 1, Kbase + (cur ^ 1) * KBYTES);
 
         // ---- S^T = K Q^T : KT tiles of [32 keys x 32 queries]
         f32x16 st[KT];
@@ -132,7 +140,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
                 for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
         }
 
-        // ---- V^T chunk: registers -> LDS (padded pitch), visible to every wave after the barrier
+        // ---- V^T chunk ch: registers (loaded during the previous chunk) -> LDS (padded pitch); its buffer was last read by
+        // the PV MFMAs of chunk ch-2 (ch-1 with a single buffer): over for every wave since the barrier above
 #pragma unroll
         for (int it = 0; it < PER_THREAD; ++it) {
             const int pidx = it * (NW * 64) + threadIdx.x;
@@ -141,7 +150,15 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
             dst[0] = make_uint2(vreg[it][0], vreg[it][1]);
             dst[1] = make_uint2(vreg[it][2], vreg[it][3]);
         }
-        __syncthreads();
+        // (raw barrier: __syncthreads() would also drain the K DMA of the next chunk, which is in flight here)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 < nchunks) {
+            if (nbuf == 1) stage_k(ch + 1, Kbase);     // single buffer: every wave is past its score MFMAs (barrier above)
+            load_v(ch + 1);                           // lands under the PV MFMAs below and the next chunk's scores
+        }
 
         // ---- P = exp2(s' - m), O^T += V^T P^T
 #pragma unroll
@@ -336,15 +353,17 @@ void launch_attn1(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok
 template <int KT, int NW>
 void launch_kt(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
     constexpr int KC = KT * 32;
-    const int lds = KC * 128 + 64 * (KC * 2 + 8);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const bool dbuf_on = !(getenv("TLD_ATTN_DBUF") && atoi(getenv("TLD_ATTN_DBUF")) == 0);     // A/B knob
+    const int nbuf = (ntok > KC && dbuf_on && 2 * (KC * 128 + 64 * (KC * 2 + 8)) <= 160 * 1024) ? 2 : 1;
+    const int lds = nbuf * (KC * 128 + 64 * (KC * 2 + 8));
+    static int attr_lds = 0;
+    if (attr_lds < lds) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<KT, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
+        attr_lds = lds;
     }
     dim3 grid(ntok / (NW * 32), heads, batch), block(NW * 64);
-    hipLaunchKernelGGL((attn_kernel<KT, NW>), grid, block, lds, s, qk, vt, att, ntok, heads * 64);
+    hipLaunchKernelGGL((attn_kernel<KT, NW>), grid, block, lds, s, qk, vt, att, ntok, heads * 64, nbuf);
 }
 
 }  // namespace
