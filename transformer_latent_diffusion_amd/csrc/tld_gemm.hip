@@ -373,7 +373,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 // 16 MFMAs each and two fragment sets (the 384-wide tile has no registers for a second set)
                 constexpr int NS = (BN == 384 || F8) ? 1 : TLD_KLOOP_NS;
                 constexpr int NI = (F8 ? 2 : 4) / NS;
-                constexpr int NDMA = (NI + 1) / 2;                 // intervals that carry tile DMA
+#ifndef TLD_KL_NDMA
+#define TLD_KL_NDMA 2       // experiment knob: R intervals of a bf16 K-step that carry tile DMA (1..3)
+#endif
+#ifndef TLD_KL_LGKM_LATE
+#define TLD_KL_LGKM_LATE 1  // fragments are waited for AFTER the barrier (the latency overlaps the barrier wait) except in the step's last interval, whose barrier frees the stage for DMA; 0 = always before (A/B: -1.5 % on the down projection)
+#endif
+                constexpr int NDMA = (NI == 4) ? TLD_KL_NDMA : (NI + 1) / 2;   // intervals that carry tile DMA
 #pragma unroll
                 for (int h = 0; h < NI; ++h) {
                     // ---- R interval   (optional s_memtime trace: 4 stamps per interval pair, see tld_debug_gemm_bench)
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         }
                     }
                     if (h == NI - 1) wait_vmcnt<0>();
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (!TLD_KL_LGKM_LATE || h == NI - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     stamp4(1);
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
