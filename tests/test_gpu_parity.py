@@ -229,6 +229,29 @@ def test_edge_batches_and_engine_growth():
         m(x[:, :3], s, lab)                             # wrong channel count
 
 
+def test_abi_error_paths_on_device():
+    """Call-order and argument errors come back as status + message (nothing throws across the ABI, nothing crashes)."""
+    import ctypes as C
+    from transformer_latent_diffusion_amd import _lib
+    L = _lib.lib()
+    cfg = _lib.TldConfig(16, 256, 2, 768, 1, 768, 4, 4, 8, 0)
+    h = C.c_void_p()
+    assert L.tld_engine_create(C.byref(cfg), C.byref(h)) == 0
+    # incomplete state_dict: finalize names the missing entry instead of folding garbage
+    rc = L.tld_engine_finalize_weights(h)
+    assert rc != 0 and b"missing" in L.tld_last_error()
+    assert L.tld_engine_set_gemm_dtype(h, 7) != 0 and b"gemm dtype" in L.tld_last_error()
+    assert L.tld_engine_set_gemm_dtype(h, 1) == 0 and L.tld_engine_set_gemm_dtype(h, 0) == 0
+    assert L.tld_engine_destroy(h) == 0
+    # the operand type is fixed once weights are packed
+    g = load_golden("g3_tiny16_forward.npz")
+    cfg_, sd, m = _engine(g)
+    m.reserve(4)
+    assert L.tld_engine_set_gemm_dtype(m._engine, 1) != 0 and b"before" in L.tld_last_error()
+    bad = _lib.TldConfig(16, 256, 2, 1024, 1, 768, 4, 4, 8, 0)            # d = 1024: the row kernels' LDS tables do not fit
+    assert L.tld_engine_create(C.byref(bad), C.byref(h)) != 0 and b"LDS" in L.tld_last_error()
+
+
 def test_bf16_io_matches_fp32_io():
     g = load_golden("g1_tiny32_forward.npz")
     cfg, sd, m = _engine(g)

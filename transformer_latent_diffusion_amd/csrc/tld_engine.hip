@@ -534,13 +534,30 @@ int tld_engine_finalize_weights(tld_engine* e) {
     for (int l = 0; l < e->L; ++l) {
         Layer& Ly = e->layers[l];
 #define LK(suffix) (snprintf(key, sizeof(key), "denoiser_trans_block.decoder_blocks.%d.%s", l, suffix), key)
-        if (int rc = upload_bf16(e, LK("self_attention.qkv_linear.weight"), &Ly.qkv_w, 3 * d * d)) return rc;
+        // bf16 GEMM operands: only the copies this engine's paths read are made resident (the LayerNorm folds use gamma-scaled
+        // copies built below, the fp8 mode its own e4m3 ones); presence and size of the three matrices are checked either way
+        {
+            const struct { const char* suffix; int64_t n; } need[3] = {{"self_attention.qkv_linear.weight", 3 * d * d},
+                                                                       {"mlp.mlp.0.weight", hid * d}, {"mlp.mlp.3.weight", d * hid}};
+            for (const auto& nd : need) {
+                auto it = e->host.find(LK(nd.suffix));
+                if (it == e->host.end()) return fail(TLD_ERR_STATE, "state_dict entry missing: %s", key);
+                if ((int64_t)it->second.data.size() != nd.n)
+                    return fail(TLD_ERR_SHAPE, "%s: expected %lld elements, got %lld", key, (long long)nd.n, (long long)it->second.data.size());
+            }
+            for (const char* sfx : {"norm1.weight", "norm1.bias", "norm3.weight", "norm3.bias", "mlp.mlp.0.bias", "mlp.mlp.1.bias"})
+                if (e->host.find(LK(sfx)) == e->host.end()) return fail(TLD_ERR_STATE, "state_dict entry missing: %s", key);
+        }
+        if (!e->fold_ln1 && !e->fp8)
+            if (int rc = upload_bf16(e, LK("self_attention.qkv_linear.weight"), &Ly.qkv_w, 3 * d * d)) return rc;
         if (int rc = upload_f32(e, LK("cross_attention.kv_linear.weight"), &Ly.kv_w, 2 * d * d)) return rc;
         if (int rc = upload_f32(e, LK("cross_attention.q_linear.weight"), &Ly.q_w, d * d)) return rc;
-        if (int rc = upload_bf16(e, LK("mlp.mlp.0.weight"), &Ly.up_w, hid * d)) return rc;
+        if (!e->fold_ln3 && !e->fp8)
+            if (int rc = upload_bf16(e, LK("mlp.mlp.0.weight"), &Ly.up_w, hid * d)) return rc;
         if (int rc = upload_f32(e, LK("mlp.mlp.0.bias"), &Ly.up_b, hid)) return rc;
         if (int rc = upload_f32(e, LK("mlp.mlp.1.bias"), &Ly.dw_b, hid)) return rc;
-        if (int rc = upload_bf16(e, LK("mlp.mlp.3.weight"), &Ly.down_w, d * hid)) return rc;
+        if (!e->fp8)
+            if (int rc = upload_bf16(e, LK("mlp.mlp.3.weight"), &Ly.down_w, d * hid)) return rc;
         if (int rc = upload_f32(e, LK("mlp.mlp.3.bias"), &Ly.down_b, d)) return rc;
         if (int rc = upload_f32(e, LK("norm1.weight"), &Ly.n1_w, d)) return rc;
         if (int rc = upload_f32(e, LK("norm1.bias"), &Ly.n1_b, d)) return rc;
