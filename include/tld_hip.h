@@ -138,6 +138,62 @@ TLD_API int64_t tld_engine_weight_bytes(const tld_engine* e);
 
 TLD_API int tld_engine_destroy(tld_engine* e);
 
+/* ---- VAE decode of the final latents --------------------------------------------------
+ * Replaces `self.vae.decode(latents)[0]` at tld/diffusion.py:91, where `vae` is diffusers' AutoencoderKL
+ * ("madebyollin/sdxl-vae-fp16-fix", tld/configs.py:39-43; a third-party dependency that is not part of the reference
+ * checkout -- the algorithm restated here is AutoencoderKL.decode of diffusers 0.2x: post_quant_conv -> Decoder
+ * (conv_in, UNetMidBlock2D with one single-head attention, UpDecoderBlock2D x n, GroupNorm + SiLU, conv_out)).
+ * Activations are bf16 channels-last on the device, GroupNorm statistics / softmax / accumulation fp32. */
+typedef struct tld_vae tld_vae;
+
+typedef struct tld_vae_config {
+    int32_t latent_channels;        /* 4 */
+    int32_t out_channels;           /* 3 */
+    int32_t n_blocks;               /* entries of block_out_channels in use (<= 4) */
+    int32_t block_out_channels[4];  /* AutoencoderKL order, e.g. 128, 256, 512, 512; each in {64,128,256,512,1024} */
+    int32_t layers_per_block;       /* 2: every decoder up block has layers_per_block + 1 resnets */
+    int32_t norm_num_groups;        /* 32 */
+    int32_t mid_block_attention;    /* 1 */
+    int32_t use_post_quant_conv;    /* 1 */
+    int32_t latent_size;            /* h = w of the latent image (32 for 256 px output) */
+    int32_t max_batch;              /* largest batch one tld_vae_decode call will see */
+    int32_t device_id;
+} tld_vae_config;
+
+TLD_API int tld_vae_create(const tld_vae_config* cfg, tld_vae** out);
+
+/* AutoencoderKL.load_state_dict, one entry at a time (diffusers key names: "decoder.conv_in.weight",
+ * "decoder.mid_block.attentions.0.to_q.weight" or its pre-0.19 spelling "...query.weight", "post_quant_conv.bias" ...).
+ * "encoder.*" and "quant_conv.*" entries are accepted and ignored.  Host fp32 data. */
+TLD_API int tld_vae_load_tensor(tld_vae* v, const char* key, const void* host_ptr, const int64_t* shape, int32_t ndim,
+                                int32_t dtype);
+TLD_API int tld_vae_finalize_weights(tld_vae* v);
+
+/* AutoencoderKL.decode(z)[0] -- tld/diffusion.py:91.
+ *   z    [batch, latent_channels, h, w]   device, io_dtype (already multiplied by the caller's scale factor)
+ *   out  [batch, out_channels, 8h, 8w]    device, fp32 (2^(n_blocks-1) x upsampling) */
+TLD_API int tld_vae_decode(tld_vae* v, const void* z, float* out, int32_t batch, int32_t io_dtype, void* hip_stream);
+
+/* Test hook: with debug enabled, decode keeps a copy of the activation after every stage; read_stage converts one to
+ * host fp32 [batch, C, H, W].  names: "conv_in", "mid.res0", "mid.attn", "mid.res1", "up<i>.res<j>", "up<i>.upsample",
+ * "norm_out".  shape4 (optional) receives batch, C, H, W. */
+TLD_API int tld_vae_set_debug(tld_vae* v, int32_t enable);
+TLD_API int tld_vae_read_stage(tld_vae* v, const char* name, float* host_out, int64_t numel, int64_t* shape4);
+
+/* Live timing of one kernel class of the decoder (HIP events around every launch, like tld_engine_set_profile).
+ * classes: 0 conv3x3, 1 gemm (1x1 / attention), 2 groupnorm, 3 other */
+TLD_API int tld_vae_set_profile(tld_vae* v, int32_t enable);
+TLD_API int tld_vae_get_profile(tld_vae* v, int32_t kclass, double* total_ms, int64_t* launches);
+
+/* Test hook: the implicit-GEMM 3x3 convolution alone (zero padding 1, stride 1; up = 1: nearest 2x upsampling folded in).
+ *   in  bf16 channels-last [B, H >> up, W >> up, cin] (device);  w  bf16 [cout][3][3][cin] (device)
+ *   out fp32 [B*H*W][cout] (device).  cin % 64 == 0.  Synchronises the stream. */
+TLD_API int tld_debug_conv3x3(const void* in_bf16, const void* w_bf16, float* out_f32, int32_t B, int32_t H, int32_t W,
+                              int32_t cin, int32_t cout, int32_t up, void* hip_stream);
+
+TLD_API int64_t tld_vae_weight_bytes(const tld_vae* v);
+TLD_API int tld_vae_destroy(tld_vae* v);
+
 TLD_API const char* tld_last_error(void);
 
 #ifdef __cplusplus

@@ -23,14 +23,26 @@ ABI_SYMBOLS = (
     "tld_sample", "tld_engine_set_gemm_dtype", "tld_debug_quant_mx8", "tld_debug_quant_mx8_host", "tld_debug_gemm_mx8",
     "tld_engine_set_debug", "tld_engine_read_stage", "tld_debug_gemm_bf16", "tld_debug_gemm_bench",
     "tld_engine_set_profile", "tld_engine_profile_reserve", "tld_engine_get_profile", "tld_engine_weight_bytes", "tld_engine_destroy",
+    "tld_vae_create", "tld_vae_load_tensor", "tld_vae_finalize_weights", "tld_vae_decode", "tld_vae_set_debug",
+    "tld_vae_read_stage", "tld_vae_set_profile", "tld_vae_get_profile", "tld_debug_conv3x3", "tld_vae_weight_bytes",
+    "tld_vae_destroy",
     "tld_last_error",
 )
+
+VAE_KERNEL_CLASSES = ("conv3x3", "gemm", "groupnorm", "other")
 
 
 class TldConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("image_size", "noise_embed_dims", "patch_size", "embed_dim", "n_layers",
                                          "text_emb_size", "n_channels", "mlp_multiplier", "max_batch",
                                          "device_id")]
+
+
+class TldVaeConfig(C.Structure):
+    _fields_ = [("latent_channels", C.c_int32), ("out_channels", C.c_int32), ("n_blocks", C.c_int32),
+                ("block_out_channels", C.c_int32 * 4), ("layers_per_block", C.c_int32), ("norm_num_groups", C.c_int32),
+                ("mid_block_attention", C.c_int32), ("use_post_quant_conv", C.c_int32), ("latent_size", C.c_int32),
+                ("max_batch", C.c_int32), ("device_id", C.c_int32)]
 
 
 _lib = None
@@ -78,8 +90,20 @@ def lib() -> C.CDLL:
     L.tld_engine_weight_bytes.argtypes = [vp]
     L.tld_engine_weight_bytes.restype = C.c_int64
     L.tld_engine_destroy.argtypes = [vp]
+    L.tld_vae_create.argtypes = [C.POINTER(TldVaeConfig), C.POINTER(vp)]
+    L.tld_vae_load_tensor.argtypes = [vp, C.c_char_p, vp, i64p, i32, i32]
+    L.tld_vae_finalize_weights.argtypes = [vp]
+    L.tld_vae_decode.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.tld_vae_set_debug.argtypes = [vp, i32]
+    L.tld_vae_read_stage.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_int64, i64p]
+    L.tld_vae_set_profile.argtypes = [vp, i32]
+    L.tld_vae_get_profile.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.tld_debug_conv3x3.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    L.tld_vae_weight_bytes.argtypes = [vp]
+    L.tld_vae_weight_bytes.restype = C.c_int64
+    L.tld_vae_destroy.argtypes = [vp]
     for name in ABI_SYMBOLS:
-        if name not in ("tld_last_error", "tld_engine_weight_bytes"):
+        if name not in ("tld_last_error", "tld_engine_weight_bytes", "tld_vae_weight_bytes"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

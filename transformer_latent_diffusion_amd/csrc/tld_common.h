@@ -242,6 +242,16 @@ struct GemmParams {
     int f8;
     const uint8_t* a_scale;
     const uint8_t* w_scale;
+    // Implicit 3x3 convolution (conv != 0; VAE decoder, tld_vae.hip): the A operand is never materialised.  Row m of the GEMM is
+    // output pixel (b, y, x) of a channels-last [B, cv_h, cv_w, *] image, K = 9 cv_cin with k = tap * cv_cin + c (tap = 3 ky + kx,
+    // W laid out [N][3][3][cv_cin]), and K-step k of a tile is DMA'd from the 128-byte channel slice of source pixel
+    // (y + ky - 1, x + kx - 1) -- or of ((y + ky - 1) >> 1, (x + kx - 1) >> 1) in a half-resolution source when cv_up (nearest
+    // 2x upsampling folded into the addressing).  A points at the activation BUFFER, whose first cv_data_off bytes are
+    // zeros (>= 2 cv_cin: one whole pixel): taps outside the image read that zero pixel, so there is no border code in
+    // the kernel.
+    // cv_cin % 64 == 0; buffer size < 4 GiB; epilogues EPI_F32, EPI_BIAS_BF16, EPI_BIAS_RESID; 256- and 128-wide tiles.
+    int conv, cv_h, cv_w, cv_up, cv_cin;
+    unsigned cv_data_off;
     unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0
     int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop
@@ -249,6 +259,9 @@ struct GemmParams {
 };
 
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s);
+
+// thread-local message behind tld_last_error() (tld_engine.hip); for the other host translation units
+void set_last_error(const char* msg);
 
 // MX-fp8 quantisation of a GEMM operand (tld_quant.hip): e4m3 elements [rows, K] + E8M0 block scales [K/128][rows][4]
 void launch_quant_mx8(const bf16* in, uint8_t* out, uint8_t* scale, int M, int K, hipStream_t s);

@@ -30,6 +30,12 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+}  // namespace
+namespace tld {
+void set_last_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); }
+}  // namespace tld
+namespace {
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
@@ -413,6 +419,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
 extern "C" {
 
 const char* tld_last_error(void) { return g_err; }
+
 
 int tld_engine_create(const tld_config* c, tld_engine** out) {
     if (!c || !out) return fail(TLD_ERR_INVALID, "null argument");

@@ -110,7 +110,9 @@ struct G256P : G256<BN> {
 // LDS image, its swizzle and every epilogue are those of the bf16 kernel; what changes is the fragment (32 bytes per
 // lane: two 16-B reads), the MFMA, and a 1-KiB strip of scale bytes per operand and K-step that travels with the tile
 // (scale layout [K/128][rows][4], see GemmParams).  Used for BASELINE config C4 (QKV / MLP GEMMs in fp8).
-template <int BN, int EPI, bool F8 = false>
+// CONV = true: implicit 3x3 convolution over a channels-last image (GemmParams::conv): only the A-side DMA addressing
+// differs -- the per-lane row offsets are recomputed whenever the K loop moves to the next of the 9 taps.
+template <int BN, int EPI, bool F8 = false, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks) {
     using G = G256P<BN>;
     using frag_t = std::conditional_t<F8, i32x8, bf16x8>;
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     constexpr int SC_OFF = G::LDS_BYTES;                                // F8: [stage][A scales 1 KiB | W scales 1 KiB] behind the stages
     static_assert(!F8 || (EPI == EPI_F32 || EPI == EPI_QKV || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID), "fp8 epilogues");
     static_assert(!F8 || TLD_KLOOP_STAGGER, "the fp8 path exists in the staggered K loop only");
+    static_assert(!CONV || (!F8 && TLD_KLOOP_STAGGER && (EPI == EPI_F32 || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID)), "conv mode");
     constexpr bool IS_QKV = EPI == EPI_QKV || EPI == EPI_QKV_LN, LN = EPI == EPI_QKV_LN;
     static_assert(8 * G::SCRATCH <= G::STAGE_BYTES, "epilogue scratch must fit in one stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -166,16 +169,53 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     };
     if (my_tiles == 0) return;
 
-    const int nk = p.K * ESZ / (G::BK * 2);                            // 128-byte K-steps
+    const int nk = CONV ? 9 * (p.cv_cin >> 6) : p.K * ESZ / (G::BK * 2);   // 128-byte K-steps
     // DMA addressing: a uniform 64-bit base (operand + K offset, SGPRs) plus one 32-bit byte offset per piece and
     // lane (row clamp, row pitch and the source-side swizzle), recomputed once per tile -- per K-step and piece the
     // only VALU work is the load itself.  (Operands are < 4 GiB: checked at launch.)
     unsigned voffA[G::A_PIECES], voffB[G::B_PIECES];
+    // CONV: output pixel (y << 16 | x) of every A row this lane brings in, and the first pixel of its sample in the source image
+    unsigned cpix[G::A_PIECES], cbase[G::A_PIECES];
+    auto conv_tap = [&](int tap) {                            // A-row offsets of one of the nine taps (uniform tap)
+        if constexpr (CONV) {
+            const int ky = tap / 3;
+            const int dy = ky - 1, dx = tap - ky * 3 - 1;
+            const int ws_ = p.cv_w >> p.cv_up;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int q2 = 0; q2 < G::A_PIECES; ++q2) {
+                const int r = (wid * G::A_PIECES + q2) * 8 + (ln >> 3);
+                const unsigned c16 = (unsigned)(((ln & 7) ^ ((r >> 1) & 7)) * 16);
+                const int yy = (int)(cpix[q2] >> 16) + dy, xx = (int)(cpix[q2] & 0xffffu) + dx;
+                const bool inb = (unsigned)yy < (unsigned)p.cv_h && (unsigned)xx < (unsigned)p.cv_w;
+                const unsigned sp = cbase[q2] + (unsigned)((yy >> p.cv_up) * ws_ + (xx >> p.cv_up));
+                unsigned v = inb ? p.cv_data_off + sp * (unsigned)(p.cv_cin * 2) + c16 : c16;     // outside: the zero page
+                asm volatile("" : "+v"(v));
+                voffA[q2] = v;
+            }
+        }
+    };
     auto set_offsets = [&](int tm0, int tn0) {
         // (the empty asm statements keep the compiler from hoisting the lane-only sub-expressions out of the tile
         // loop as 64-bit loop invariants -- it then spilled them inside the K loop)
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        if constexpr (CONV) {
+            const unsigned hw = (unsigned)(p.cv_h * p.cv_w);
+            const unsigned shw = (unsigned)((p.cv_h >> p.cv_up) * (p.cv_w >> p.cv_up));
+#pragma unroll
+            for (int q2 = 0; q2 < G::A_PIECES; ++q2) {
+                const int r = (wid * G::A_PIECES + q2) * 8 + (ln >> 3);
+                int gr = tm0 + r;
+                gr = gr < p.M ? gr : p.M - 1;
+                const unsigned b = (unsigned)gr / hw, rem = (unsigned)gr - b * hw;
+                const unsigned y = rem / (unsigned)p.cv_w, x = rem - y * (unsigned)p.cv_w;
+                cpix[q2] = (y << 16) | x;
+                cbase[q2] = b * shw;
+            }
+            conv_tap(0);
+        } else {
 #pragma unroll
         for (int q2 = 0; q2 < G::A_PIECES; ++q2) {
             const int r = (wid * G::A_PIECES + q2) * 8 + (ln >> 3);
@@ -185,6 +225,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             unsigned v = __umul24((unsigned)gr, (unsigned)(p.lda * ESZ)) + (unsigned)(clog * 16);   // rows, pitch < 2^24
             asm volatile("" : "+v"(v));
             voffA[q2] = v;
+        }
         }
 #pragma unroll
         for (int q2 = 0; q2 < G::B_PIECES; ++q2) {
@@ -258,6 +299,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     tile_coords(0, m0, n0);
     issue(m0, n0, 0);
     int g = 0;                                        // global K-step counter (ring position)
+    int ctap = 0, ccb = 0;                            // CONV: (tap, 64-channel block) of the K-step whose DMA was issued last
+    const int kpt = CONV ? (p.cv_cin >> 6) : 1;       // K-steps per tap
     for (int it = 0; it < my_tiles; ++it) {
         int m0n = 0, n0n = 0;
         const bool has_next = it + 1 < my_tiles;
@@ -367,7 +410,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
                 const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV && EPI != EPI_UP_DWCONV2);
-                const int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
+                int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
+                if constexpr (CONV) {
+                    if (k + 1 < nk) {
+                        if (++ccb == kpt) { ccb = 0; ++ctap; conv_tap(ctap); }
+                        pkb = ccb * (G::BK * 2);
+                    } else { ccb = 0; ctap = 0; }                   // (set_offsets below starts the next tile at tap 0)
+                }
                 if (k + 1 == nk && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
                 // NS k-slices per interval: 1 -> 8 intervals (barriers) per K-step with 8 (12) MFMAs each; 2 -> 4 intervals with
                 // 16 MFMAs each and two fragment sets (the 384-wide tile has no registers for a second set)
@@ -1037,7 +1086,8 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     GemmParams pg = p;
     if ((epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
         pg.xcd_ngroups = 2;
-#define TLD_L256P_(E, F8)                                                                             \
+#define TLD_L256P_(E, F8) TLD_L256P__(E, F8, false)
+#define TLD_L256P__(E, F8, CV)                                                                        \
     do {                                                                                              \
         constexpr int lds = (F8) ? G::LDS_BYTES + 4096                                                \
                             : ((E) == EPI_UP_DWCONV && G::UPDW_LDS > G::LDS_BYTES ? G::UPDW_LDS       \
@@ -1046,14 +1096,23 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
                             : ((E) == EPI_BIAS_BF16 ? G::PLAINLN_LDS : G::LDS_BYTES))));              \
         static bool once = false;                                                                     \
         if (!once) {                                                                                  \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E, F8>),            \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E, F8, CV>),        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
             once = true;                                                                              \
         }                                                                                             \
-        hipLaunchKernelGGL((gemm256p_kernel<BN, E, F8>), grid, block, lds, s, pg, nblocks);           \
+        hipLaunchKernelGGL((gemm256p_kernel<BN, E, F8, CV>), grid, block, lds, s, pg, nblocks);       \
     } while (0)
 #define TLD_L256P(E) TLD_L256P_(E, false)
-    if (p.f8) {             // MX-fp8 operands: 256- or 128-wide tiles with four epilogues, 192-wide for the residual add
+    if (p.conv) {           // implicit 3x3 convolution (VAE decoder): 256- or 128-wide tiles, three epilogues
+        if constexpr (BN == 256 || BN == 128) {
+            switch (epilogue) {
+                case EPI_F32: TLD_L256P__(EPI_F32, false, true); break;
+                case EPI_BIAS_BF16: TLD_L256P__(EPI_BIAS_BF16, false, true); break;
+                case EPI_BIAS_RESID: TLD_L256P__(EPI_BIAS_RESID, false, true); break;
+                default: break;
+            }
+        }
+    } else if (p.f8) {      // MX-fp8 operands: 256- or 128-wide tiles with four epilogues, 192-wide for the residual add
         if constexpr (BN == 256 || BN == 128) {
             switch (epilogue) {
                 case EPI_F32: TLD_L256P_(EPI_F32, true); break;
@@ -1079,6 +1138,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
             default: break;
         }
     }
+#undef TLD_L256P__
 #undef TLD_L256P_
 #undef TLD_L256P
 }
@@ -1123,6 +1183,10 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
     const GemmParams& p = p_in;
 #endif
     int bn = choose_bn(p.M, p.N, epilogue);
+    if (p.conv) {           // 256-wide tiles when the width allows and they fill the chip, else 128
+        const long ntm = (p.M + 255) / 256;
+        bn = (p.N % 256 == 0 && ntm * (p.N / 256) >= 192) ? 256 : 128;
+    }
     if (p.f8) {             // the fp8 kernel is instantiated for 256 / 128 (all epilogues) and 192 (residual add: N = 768 in whole rounds)
         const long ntm = (p.M + 255) / 256;
         if (epilogue == EPI_BIAS_RESID && p.N % 192 == 0 && ((ntm * (p.N / 192)) % 256 == 0 || p.N % 256 != 0)) bn = 192;
