@@ -238,9 +238,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             voffB[q2] = v;
         }
     };
+    int conv_akb = 0;                                         // CONV: byte offset of the K-step's 64-channel block inside a pixel (A side)
     auto dma_piece = [&](int q2, int kbyte, char* st) {       // q2 < A_PIECES: A piece, else W piece; kbyte uniform
         if (q2 < G::A_PIECES) {
-            const char* base = reinterpret_cast<const char*>(p.A) + kbyte;
+            const char* base = reinterpret_cast<const char*>(p.A) + (CONV ? conv_akb : kbyte);
             __builtin_amdgcn_global_load_lds((gptr_t)(base + voffA[q2]), (lptr_t)(st + (wid * G::A_PIECES + q2) * 1024), 16, 0, TLD_GLDS_AUX);
         } else {
             const char* base = reinterpret_cast<const char*>(p.W) + kbyte;
@@ -410,12 +411,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
                 const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV && EPI != EPI_UP_DWCONV2);
-                int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
+                const int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
                 if constexpr (CONV) {
                     if (k + 1 < nk) {
                         if (++ccb == kpt) { ccb = 0; ++ctap; conv_tap(ctap); }
-                        pkb = ccb * (G::BK * 2);
                     } else { ccb = 0; ctap = 0; }                   // (set_offsets below starts the next tile at tap 0)
+                    conv_akb = ccb * (G::BK * 2);
                 }
                 if (k + 1 == nk && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
                 // NS k-slices per interval: 1 -> 8 intervals (barriers) per K-step with 8 (12) MFMAs each; 2 -> 4 intervals with

@@ -147,12 +147,16 @@ __global__ __launch_bounds__(256) void vae_gn_stats_kernel(const bf16* __restric
     }
 }
 // stage 2: (mean, rstd) per (sample, group); the chunk partials are combined in fp64 (E[x^2] - mean^2 loses nothing there)
+// (eight threads per group, each summing every eighth chunk; the order is fixed, so the result is reproducible)
 __global__ void vae_gn_finalize_kernel(const float2* __restrict__ partial, int nchunk, int G, double inv_n, float eps,
                                        float2* __restrict__ stats) {
-    const int b = blockIdx.x, g = threadIdx.x;
+    const int b = blockIdx.x, g = threadIdx.x >> 3, part = threadIdx.x & 7;
     if (g >= G) return;
     double a = 0.0, a2 = 0.0;
-    for (int c = 0; c < nchunk; ++c) { const float2 t = partial[((size_t)b * nchunk + c) * G + g]; a += (double)t.x; a2 += (double)t.y; }
+    for (int c = part; c < nchunk; c += 8) { const float2 t = partial[((size_t)b * nchunk + c) * G + g]; a += (double)t.x; a2 += (double)t.y; }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o); a2 += __shfl_xor(a2, o); }
+    if (part) return;
     const double mean = a * inv_n;
     double var = a2 * inv_n - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -282,7 +286,12 @@ struct tld_vae {
     float* io_z = nullptr;
     float2 *gn_partial = nullptr, *gn_stats = nullptr;
     int gn_max_chunks = 0;
-    float* scores = nullptr; bf16* probs = nullptr; bf16* vt = nullptr;
+    // mid-block attention: the per-sample chains (scores, softmax, V^T, P V) are small launches (16 tiles each); they run
+    // round-robin on kAttnStreams side streams, each with its own scratch, forked from / joined to the caller's stream
+    static constexpr int kAttnStreams = 4;
+    float* scores[kAttnStreams] = {}; bf16* probs[kAttnStreams] = {}; bf16* vt[kAttnStreams] = {};
+    hipStream_t side[kAttnStreams] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[kAttnStreams] = {};
     float* out_f32 = nullptr;
 
     bool debug = false;
@@ -411,7 +420,7 @@ int group_norm(tld_vae* v, int src, int dst, const GnW& gn, int B, int HW, int C
     const int TPP = C / 8, PPI = 256 / TPP;
     const size_t lds = (size_t)(PPI * C + C) * sizeof(float2);
     hipLaunchKernelGGL(vae_gn_stats_kernel, dim3(nchunk, B), dim3(256), lds, s, v->data(src), HW, C, v->G, ppb, v->gn_partial);
-    hipLaunchKernelGGL(vae_gn_finalize_kernel, dim3(B), dim3(64), 0, s, v->gn_partial, nchunk, v->G,
+    hipLaunchKernelGGL(vae_gn_finalize_kernel, dim3(B), dim3(v->G * 8), 0, s, v->gn_partial, nchunk, v->G,
                        1.0 / ((double)HW * (C / v->G)), kGnEps, v->gn_stats);
     if (silu) hipLaunchKernelGGL(vae_gn_apply_kernel<true>, dim3(nchunk, B), dim3(256), 0, s, v->data(src), v->gn_stats, gn.g, gn.b, v->data(dst), HW, C, v->G, ppb);
     else hipLaunchKernelGGL(vae_gn_apply_kernel<false>, dim3(nchunk, B), dim3(256), 0, s, v->data(src), v->gn_stats, gn.g, gn.b, v->data(dst), HW, C, v->G, ppb);
@@ -496,17 +505,30 @@ int attention(tld_vae* v, int* xi, int B, int H, int W, int C, hipStream_t s) {
     if (int rc = group_norm(v, x, t, v->attn_gn, B, HW, C, false, s)) return rc;
     if (int rc = gemm(v, v->data(t), C, v->attn_qkv.w, C, M, 3 * C, C, EPI_BIAS_BF16, v->attn_qkv.b, v->data(qkv), 3 * C, nullptr, s)) return rc;
     const float scale = 1.0f / sqrtf((float)C);
+    // with live profiling the chains stay on the caller's stream (the class timers bracket launches on one stream)
+    const int ns = v->profile ? 1 : std::min<int>(tld_vae::kAttnStreams, B);
+    if (ns > 1) {
+        HIP_TRY(hipEventRecord(v->fork_ev, s));
+        for (int i = 0; i < ns; ++i) HIP_TRY(hipStreamWaitEvent(v->side[i], v->fork_ev, 0));
+    }
     for (int b = 0; b < B; ++b) {
+        const int si = b % ns;
+        hipStream_t st = ns > 1 ? v->side[si] : s;
         const bf16* q = v->data(qkv) + (size_t)b * HW * 3 * C;
-        if (int rc = gemm(v, q, 3 * C, q + C, 3 * C, HW, HW, C, EPI_F32, nullptr, nullptr, HW, v->scores, s)) return rc;
+        if (int rc = gemm(v, q, 3 * C, q + C, 3 * C, HW, HW, C, EPI_F32, nullptr, nullptr, HW, v->scores[si], st)) return rc;
         {
-            Timer tm(v, VC_OTHER, s);
-            hipLaunchKernelGGL(vae_softmax_rows_kernel, dim3(HW), dim3(256), 0, s, v->scores, v->probs, HW, scale);
-            hipLaunchKernelGGL(vae_transpose_kernel, dim3((C + 31) / 32, (HW + 31) / 32), dim3(32, 8), 0, s, q + 2 * C, 3 * C, v->vt, HW, HW, C);
+            Timer tm(v, VC_OTHER, st);
+            hipLaunchKernelGGL(vae_softmax_rows_kernel, dim3(HW), dim3(256), 0, st, v->scores[si], v->probs[si], HW, scale);
+            hipLaunchKernelGGL(vae_transpose_kernel, dim3((C + 31) / 32, (HW + 31) / 32), dim3(32, 8), 0, st, q + 2 * C, 3 * C, v->vt[si], HW, HW, C);
         }
         // o_b = P V  (tokens of sample b of buffer t, which the projections no longer need)
-        if (int rc = gemm(v, v->probs, HW, v->vt, HW, HW, C, HW, EPI_BIAS_BF16, v->zero_bias, v->data(t) + (size_t)b * HW * C, C, nullptr, s)) return rc;
+        if (int rc = gemm(v, v->probs[si], HW, v->vt[si], HW, HW, C, HW, EPI_BIAS_BF16, v->zero_bias, v->data(t) + (size_t)b * HW * C, C, nullptr, st)) return rc;
     }
+    if (ns > 1)
+        for (int i = 0; i < ns; ++i) {
+            HIP_TRY(hipEventRecord(v->join_ev[i], v->side[i]));
+            HIP_TRY(hipStreamWaitEvent(s, v->join_ev[i], 0));
+        }
     if (int rc = gemm(v, v->data(t), C, v->attn_out.w, C, M, C, C, EPI_BIAS_RESID, v->attn_out.b, v->data(x), C, nullptr, s)) return rc;
     return check_launch("attention");
 }
@@ -580,9 +602,14 @@ int tld_vae_create(const tld_vae_config* cfg, tld_vae** out) {
     if (int rc = dev_alloc(v, &v->gn_stats, (size_t)cfg->max_batch * v->G)) return bail(rc);
     if (cfg->mid_block_attention) {
         const size_t hw = (size_t)v->hl * v->hl;
-        if (int rc = dev_alloc(v, &v->scores, hw * hw)) return bail(rc);
-        if (int rc = dev_alloc(v, &v->probs, hw * hw)) return bail(rc);
-        if (int rc = dev_alloc(v, &v->vt, hw * v->C0)) return bail(rc);
+        for (int i = 0; i < tld_vae::kAttnStreams; ++i) {
+            if (int rc = dev_alloc(v, &v->scores[i], hw * hw)) return bail(rc);
+            if (int rc = dev_alloc(v, &v->probs[i], hw * hw)) return bail(rc);
+            if (int rc = dev_alloc(v, &v->vt[i], hw * v->C0)) return bail(rc);
+            if (hipStreamCreateWithFlags(&v->side[i], hipStreamNonBlocking) != hipSuccess) return bail(fail(TLD_ERR_HIP, "hipStreamCreate failed"));
+            if (hipEventCreateWithFlags(&v->join_ev[i], hipEventDisableTiming) != hipSuccess) return bail(fail(TLD_ERR_HIP, "hipEventCreate failed"));
+        }
+        if (hipEventCreateWithFlags(&v->fork_ev, hipEventDisableTiming) != hipSuccess) return bail(fail(TLD_ERR_HIP, "hipEventCreate failed"));
     }
     if (int rc = dev_alloc(v, &v->out_f32, (size_t)cfg->max_batch * Hout * Hout * v->oc)) return bail(rc);
     *out = v;
@@ -808,6 +835,11 @@ int tld_vae_destroy(tld_vae* v) {
     clear_stages(v);
     for (int k = 0; k < VC_COUNT; ++k)
         for (auto& e : v->ev[k]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (int i = 0; i < tld_vae::kAttnStreams; ++i) {
+        if (v->side[i]) { (void)hipStreamSynchronize(v->side[i]); (void)hipStreamDestroy(v->side[i]); }
+        if (v->join_ev[i]) (void)hipEventDestroy(v->join_ev[i]);
+    }
+    if (v->fork_ev) (void)hipEventDestroy(v->fork_ev);
     for (void* p : v->allocs) (void)hipFree(p);
     delete v;
     return TLD_OK;

@@ -235,9 +235,9 @@ class AutoencoderKLDecoder:
     def _ensure_engine(self, device: torch.device, latent_size: int, batch: int):
         if device.type != "cuda":
             raise RuntimeError("AutoencoderKLDecoder.decode needs a HIP device (tensors on 'cuda'); there is no CPU path")
-        nb = min(self.max_batch, batch)
+        nb = self.max_batch                       # (sized once: a smaller first batch must not rebuild the engine later)
         key = (device.index or 0, latent_size)
-        if self._engine is not None and self._engine_key[:2] == key and self._engine_key[2] >= nb:
+        if self._engine is not None and self._engine_key[:2] == key and self._engine_key[2] == nb:
             return
         self._drop_engine()
         L = _lib.lib()
