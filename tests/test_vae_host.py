@@ -176,3 +176,24 @@ def test_decode_has_no_cpu_path():
     with pytest.raises(ValueError):
         vae.decode(torch.zeros(1, 3, 8, 8))
     assert math.isclose(VaeDecoderConfig().upscale, 8)
+
+
+def test_load_vae_checkpoint_reads_a_diffusers_directory(tmp_path):
+    import json
+    from safetensors.torch import save_file
+    from transformer_latent_diffusion_amd.vae import load_vae_checkpoint
+    sd = {k: torch.from_numpy(v) for k, v in synth_vae_state_dict(TINY, 2).items()}
+    sd["encoder.conv_in.weight"] = torch.zeros(4, 3, 3, 3)
+    d = tmp_path / "vae"
+    d.mkdir()
+    save_file(sd, str(d / "diffusion_pytorch_model.safetensors"))
+    (d / "config.json").write_text(json.dumps({"_class_name": "AutoencoderKL", "block_out_channels": [64, 128], "layers_per_block": 1,
+                                               "latent_channels": 4, "out_channels": 3, "norm_num_groups": 32, "scaling_factor": 0.13025}))
+    got, cfg = load_vae_checkpoint(str(d))
+    assert cfg == TINY
+    vae = AutoencoderKLDecoder(cfg).load_state_dict(got)
+    assert all(torch.equal(vae.state_dict()[k], v) for k, v in sd.items() if not k.startswith("encoder."))
+    got2, cfg2 = load_vae_checkpoint(str(d / "diffusion_pytorch_model.safetensors"))
+    assert cfg2 is None and set(got2) == set(got)
+    with pytest.raises(FileNotFoundError):
+        load_vae_checkpoint(str(tmp_path))
