@@ -5,6 +5,10 @@
 // heads are contiguous 64-wide column groups ("bs n (h d) -> bs h n d", :35).  The merged-heads
 // output is written as bf16 [M, d]; the residual add happens in the following row kernel.
 //
+// Input layout: q | k row-major [M, 2d] as the QKV GEMM's epilogue writes them (a head's K is 128-byte pieces 3 KB apart; a
+// head-major [sample][q, k][head][token][64] layout was measured and changes nothing: profiles/r02_attention_experiments.txt),
+// V^T [sample][head * 64 + c][token].
+//
 // Work split: one workgroup per (sample, head, block of 32*NW query rows); each wave owns 32 query
 // rows.  Keys/values are processed in chunks of 32*KT keys staged once per workgroup in LDS:
 //   K chunk  [keys][64]  bf16, 128-B rows, DMA'd with global_load_lds using the same source-side
@@ -28,6 +32,15 @@ namespace {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+
+// -DTLD_ATTN_DBG=1 / 2: cost-attribution builds of the 256-token kernel (1: loads, score MFMAs, row max and stores only; 2: loads
+// and stores only; 3: everything but the stores) -- wrong results by construction, for tools/ab_r2u.sh
+#ifndef TLD_ATTN_DBG
+#define TLD_ATTN_DBG 0
+#endif
+#ifndef TLD_ATTN_ST16
+#define TLD_ATTN_ST16 2       // 256-token kernel's output stores: 2 = whole 128-byte rows via an LDS transpose, 1 = 16-byte stores after a lane-pair exchange, 0 = 8-byte stores
+#endif
 
 constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;   // (1/sqrt(64)) * log2(e)
 
@@ -189,17 +202,24 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
     // ---- normalise and store O^T: lane's query row, 4 consecutive features per register group
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    bf16* op = att + (row_base + q0 + l31) * d + h * 64 + 4 * hi;
+    // 16-byte stores: lane pairs (l, l ^ 32) trade their odd / even feature quads (see attn1_kernel for the measurements)
+    bf16* op = att + (row_base + q0 + l31) * d + h * 64 + 8 * hi;
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            bf16x4 pk;
+        for (int pr = 0; pr < 2; ++pr) {
+            union { bf16x4 v; unsigned u[2]; } x, y;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) pk[e] = (bf16)(o[ct][rq * 4 + e] * inv);
-            *reinterpret_cast<bf16x4*>(op + ct * 32 + rq * 8) = pk;
+            for (int e = 0; e < 4; ++e) {
+                x.v[e] = (bf16)(o[ct][(2 * pr) * 4 + e] * inv);
+                y.v[e] = (bf16)(o[ct][(2 * pr + 1) * 4 + e] * inv);
+            }
+            const auto s0 = __builtin_amdgcn_permlane32_swap(x.u[0], y.u[0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(x.u[1], y.u[1], false, false);
+            u32x4 w;
+            w[0] = s0[0]; w[1] = s1[0]; w[2] = s0[1]; w[3] = s1[1];
+            *reinterpret_cast<u32x4*>(op + ct * 32 + pr * 16) = w;
         }
-    }
 }
 
 // Single-chunk specialisation (ntok == 32*KT <= 256, the 256 px case): 4-wave workgroups that walk QT query
@@ -207,7 +227,11 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
 // LDS, 8 waves).  The two are not synchronised with each other, so one's softmax (VALU/exp bound: ~2x the MFMA
 // time of a tile) overlaps the other's MFMAs and staging -- with one 8-wave workgroup per CU every wave was in
 // the same phase.
-template <int KT, int NW, int QT>
+// PIPE: the LDS fragment reads of both MFMA phases are software-pipelined one step ahead (scores: the four K fragments of
+// the next (tile pair, k half); P V: the two V^T fragments of the next 16-key step).  In the plain form the compiler issues
+// every fragment read right in front of its MFMA (ISA: ds_read ... ~10 VALU ... s_waitcnt ... v_mfma), so each of the 32
+// steps of a query tile exposes an LDS round trip under 8 contending waves.
+template <int KT, int NW, int QT, bool PIPE>
 __global__ __launch_bounds__(NW * 64, 2) void attn1_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ vt,
                                                         bf16* __restrict__ att, int ntok, int d) {
     constexpr int KC = KT * 32;
@@ -263,6 +287,46 @@ __global__ __launch_bounds__(NW * 64, 2) void attn1_kernel(const bf16* __restric
         for (int ks = 0; ks < 4; ++ks) qf[ks] = qnext[ks];
         if (qt + 1 < QT) load_q(qt + 1, qnext);
         f32x16 st[KT];
+        if constexpr (TLD_ATTN_DBG == 2) {          // attribution build: no score MFMAs
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[t][r] = (float)qf[t & 3][r & 7];
+        } else if constexpr (PIPE) {
+            static_assert(KT % 2 == 0, "tile pairs");
+            auto kfrag = [&](int t, int ks) {
+                const int row = t * 32 + l31;
+                const int kc = ks * 2 + hi;
+                return *reinterpret_cast<const bf16x8*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
+            };
+            // step s = (tile pair s >> 1, k half s & 1): fragments K[2p][2h], K[2p][2h+1], K[2p+1][2h], K[2p+1][2h+1]
+            bf16x8 fa[4], fb[4];
+            auto fetch = [&](int s2, bf16x8 (&f)[4]) {
+                const int p2 = s2 >> 1, h2 = s2 & 1;
+                f[0] = kfrag(2 * p2, 2 * h2); f[1] = kfrag(2 * p2 + 1, 2 * h2);
+                f[2] = kfrag(2 * p2, 2 * h2 + 1); f[3] = kfrag(2 * p2 + 1, 2 * h2 + 1);
+            };
+            auto fire = [&](int s2, const bf16x8 (&f)[4]) {
+                const int p2 = s2 >> 1, h2 = s2 & 1;
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                st[2 * p2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], qf[2 * h2], h2 ? st[2 * p2] : zero, 0, 0, 0);
+                st[2 * p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], qf[2 * h2], h2 ? st[2 * p2 + 1] : zero, 0, 0, 0);
+                st[2 * p2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], qf[2 * h2 + 1], st[2 * p2], 0, 0, 0);
+                st[2 * p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[3], qf[2 * h2 + 1], st[2 * p2 + 1], 0, 0, 0);
+            };
+            fetch(0, fa);
+#pragma unroll
+            for (int s2 = 0; s2 < KT; s2 += 2) {
+                fetch(s2 + 1, fb);
+                __builtin_amdgcn_sched_barrier(0);
+                fire(s2, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s2 + 2 < KT) fetch(s2 + 2, fa);
+                __builtin_amdgcn_sched_barrier(0);
+                fire(s2 + 1, fb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
 #pragma unroll
@@ -274,6 +338,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn1_kernel(const bf16* __restric
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
                 st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[t], 0, 0, 0);
             }
+        }
         }
         float mx = st[0][0];
 #pragma unroll
@@ -299,6 +364,53 @@ __global__ __launch_bounds__(NW * 64, 2) void attn1_kernel(const bf16* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
         float l_run = 0.f;
+        if constexpr (TLD_ATTN_DBG != 0) {          // attribution build: no exponentials / P V MFMAs
+            l_run = 0.5f + m_new * 0.f;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ct][r] = st[ct][r] + st[2 + ct][r] + st[4 + ct][r] + st[6 + ct][r] + (float)*reinterpret_cast<const bf16*>(Vs + (ct * 32 + l31) * VSTRIDE + r * 2);
+        } else if constexpr (PIPE) {
+            auto vfrag = [&](int s2, int ct) {                 // step s2 = 2 t + hf: keys s2 * 16 + hi * 4 .. (+3, +8 .. +11)
+                const char* vp = Vs + (ct * 32 + l31) * VSTRIDE + (s2 * 16 + hi * 4) * 2;
+                const uint2 v0 = *reinterpret_cast<const uint2*>(vp);
+                const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
+                union { uint4 u; bf16x8 v; } cvt;
+                cvt.u = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                return cvt.v;
+            };
+            auto probs = [&](int s2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(st[s2 >> 1][(s2 & 1) * 8 + e] * kScaleLog2e - m_new);
+                    l_run += pv;
+                    pf[e] = (bf16)pv;
+                }
+                return pf;
+            };
+            bf16x8 va[2], vb[2];
+            va[0] = vfrag(0, 0); va[1] = vfrag(0, 1);
+#pragma unroll
+            for (int s2 = 0; s2 < 2 * KT; s2 += 2) {
+                vb[0] = vfrag(s2 + 1, 0); vb[1] = vfrag(s2 + 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const bf16x8 pf = probs(s2);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0], pf, o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1], pf, o[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s2 + 2 < 2 * KT) { va[0] = vfrag(s2 + 2, 0); va[1] = vfrag(s2 + 2, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const bf16x8 pf = probs(s2 + 1);
+                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[0], pf, o[0], 0, 0, 0);
+                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[1], pf, o[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
 #pragma unroll
@@ -322,31 +434,92 @@ __global__ __launch_bounds__(NW * 64, 2) void attn1_kernel(const bf16* __restric
                 }
             }
         }
+        }
         const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
-        bf16* op = att + (row_base + q0 + l31) * d + h * 64 + 4 * hi;
+#if TLD_ATTN_DBG == 3
+        if (inv > 1e30f)    // attribution build: (practically) no stores
+#endif
+        {
+#if TLD_ATTN_ST16 == 2
+            // Whole-row stores.  The MFMA leaves a lane with 4-feature pieces of ITS query row (8 bytes each; 16 bytes per row
+            // and store instruction).  This kernel is HBM-bound (200 MB per launch at C1: 26 us without the stores, 48.6 us
+            // with the direct 8-byte ones, profiles/r02_attention_experiments.txt), and the store shape is worth 10 % of it:
+            // 16-byte pieces after a lane-pair exchange 44.6 us, whole 128-byte rows 45.2 us, whole rows nontemporal 43.6 us.
+            // The tile is transposed through a 2.3-KB per-wave LDS patch, 16 rows at a time (pitch 144 B: conflict-free
+            // 8-byte writes, 16-byte aligned reads).  Wave-local: LDS operations of one wave execute in order, no barrier.
+            char* T = smem + KC * 128 + 64 * VSTRIDE + wid * (16 * 144);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+            for (int half = 0; half < 2; ++half) {
+                if ((l31 >> 4) == half) {
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                bf16x4 pk;
+                    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (bf16)(o[ct][rq * 4 + e] * inv);
-                *reinterpret_cast<bf16x4*>(op + ct * 32 + rq * 8) = pk;
+                        for (int rq = 0; rq < 4; ++rq) {
+                            bf16x4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pk[e] = (bf16)(o[ct][rq * 4 + e] * inv);
+                            *reinterpret_cast<bf16x4*>(T + (l31 & 15) * 144 + ct * 64 + rq * 16 + hi * 8) = pk;
+                        }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int r = it * 8 + (lane >> 3), c16 = lane & 7;
+                    const u32x4 w = *reinterpret_cast<const u32x4*>(T + r * 144 + c16 * 16);
+                    // (nontemporal: 45.2 -> 43.6 us; the consumer, cross_row, is not slowed by it)
+                    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(att + (row_base + q0 + half * 16 + r) * d + h * 64 + c16 * 8));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+#elif TLD_ATTN_ST16
+            // 16-byte stores: a lane owns feature quads {8 rq + 4 hi ..+3}; lane pairs (l, l ^ 32) trade the odd / even quads with
+            // v_permlane32_swap so that each ends up with 8 consecutive features (32 contiguous bytes per row and instruction
+            // instead of 16)
+            bf16* op = att + (row_base + q0 + l31) * d + h * 64 + 8 * hi;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    union { bf16x4 v; unsigned u[2]; } x, y;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x.v[e] = (bf16)(o[ct][(2 * pr) * 4 + e] * inv);
+                        y.v[e] = (bf16)(o[ct][(2 * pr + 1) * 4 + e] * inv);
+                    }
+                    // v_permlane32_swap a, b: a.upper <-> b.lower.  (x, y) -> lower lanes: own x | partner's x; upper: partner's y | own y
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(x.u[0], y.u[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(x.u[1], y.u[1], false, false);
+                    u32x4 w;
+                    w[0] = s0[0]; w[1] = s1[0]; w[2] = s0[1]; w[3] = s1[1];
+                    *reinterpret_cast<u32x4*>(op + ct * 32 + pr * 16) = w;
+                }
+#else
+            bf16* op = att + (row_base + q0 + l31) * d + h * 64 + 4 * hi;
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (bf16)(o[ct][rq * 4 + e] * inv);
+                    *reinterpret_cast<bf16x4*>(op + ct * 32 + rq * 8) = pk;
+                }
+#endif
+        }
     }
 }
 
-template <int KT, int NW, int QT>
+template <int KT, int NW, int QT, bool PIPE>
 void launch_attn1(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
     constexpr int KC = KT * 32;
-    const int lds = KC * 128 + 64 * (KC * 2 + 8);
+    const int lds = KC * 128 + 64 * (KC * 2 + 8) + (TLD_ATTN_ST16 == 2 ? NW * 16 * 144 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn1_kernel<KT, NW, QT>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn1_kernel<KT, NW, QT, PIPE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn1_kernel<KT, NW, QT>), dim3(1, heads, batch), dim3(NW * 64), lds, s, qk, vt, att, ntok,
+    hipLaunchKernelGGL((attn1_kernel<KT, NW, QT, PIPE>), dim3(1, heads, batch), dim3(NW * 64), lds, s, qk, vt, att, ntok,
                        heads * 64);
 }
 
@@ -374,7 +547,11 @@ void launch_attention(const bf16* qk, const bf16* vt, bf16* att, int batch, int 
     // workgroups, two per CU (staging overlapped with compute) -- 88 us vs 60 us per layer at C1, the K/V
     // chunk is then staged twice per head and the extra L2->LDS traffic costs more than the overlap buys.
     static const bool one_wg = getenv("TLD_ATTN_8W") && atoi(getenv("TLD_ATTN_8W")) != 0;     // A/B knob: single 8-wave workgroup per CU
-    if (ntok == 256 && !one_wg) launch_attn1<8, 4, 2>(qk, vt, att, batch, ntok, heads, s);
+    static const bool pipe = !(getenv("TLD_ATTN_PIPE") && atoi(getenv("TLD_ATTN_PIPE")) == 0);        // A/B knob: compiler-scheduled fragment reads
+    if (ntok == 256 && !one_wg) {
+        if (pipe) launch_attn1<8, 4, 2, true>(qk, vt, att, batch, ntok, heads, s);
+        else launch_attn1<8, 4, 2, false>(qk, vt, att, batch, ntok, heads, s);
+    }
     else if (ntok % 256 == 0) launch_kt<8, 8>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 128) launch_kt<4, 4>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 64) launch_kt<2, 2>(qk, vt, att, batch, ntok, heads, s);
