@@ -20,4 +20,12 @@ python profiles/summarize_rocpd.py $O/prof_c1/p_results.db $O/c1_kernel_stats.cs
 python profiles/summarize_rocpd.py $O/prof_c3/p_results.db $O/c3_kernel_stats.csv > /dev/null 2>&1
 python profiles/summarize_rocpd.py $O/prof_c4f/p_results.db $O/c4_fp8_kernel_stats.csv > /dev/null 2>&1
 timeout 600 python tools/parity_report.py > $O/parity.md 2>&1; tail -24 $O/parity.md
-rm -rf $O/prof_c1 $O/prof_c3 $O/prof_c4f $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE
+# VAE decode row: bench lines, kernel stats of the same command, per-stage parity print
+timeout 300 python tools/vae_bench.py --batch 16 --cpu-sample 1 2>&1 | grep -v amdgpu | tail -1 > $O/vae_bench_b16.json; cut -c1-400 $O/vae_bench_b16.json
+timeout 300 python tools/vae_bench.py --batch 64 2>&1 | grep -v amdgpu | tail -1 > $O/vae_bench_b64.json; cut -c1-300 $O/vae_bench_b64.json
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof_vae -o p -- python $R/tools/vae_bench.py --batch 16 --iters 2 > $R/$O/prof_vae.log 2>&1
+cd $R
+python profiles/summarize_rocpd.py $O/prof_vae/p_results.db $O/vae_kernel_stats.csv > /dev/null 2>&1; head -8 $O/vae_kernel_stats.csv | cut -c1-150
+timeout 600 python -m pytest tests/test_gpu_vae.py -q -m gpu -s -k sdxl 2>&1 | grep -E "vae stage|passed|failed" > $O/vae_parity.txt; cut -c1-300 $O/vae_parity.txt
+rm -rf $O/prof_c1 $O/prof_c3 $O/prof_c4f $O/prof_vae $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE

@@ -252,6 +252,11 @@ struct GemmParams {
     // cv_cin % 64 == 0; buffer size < 4 GiB; epilogues EPI_F32, EPI_BIAS_BF16, EPI_BIAS_RESID; 256- and 128-wide tiles.
     int conv, cv_h, cv_w, cv_up, cv_cin;
     unsigned cv_data_off;
+    // conv epilogues EPI_BIAS_BF16 / EPI_BIAS_RESID: GroupNorm statistics of the OUTPUT for its consumer, fused into the epilogue
+    // (null: none).  partial[(sample, 256-pixel chunk)][group] = (sum, sum of squares) of the stored bf16 values, gn_cpg channels per
+    // group, gn_hw pixels per sample.  Requires gn_hw % 256 == 0 (a tile never straddles samples), N % 128 == 0, gn_cpg % 4 == 0.
+    float2* gn_partial;
+    int gn_groups, gn_cpg, gn_hw;
     unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0
     int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop

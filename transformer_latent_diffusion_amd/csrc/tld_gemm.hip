@@ -589,6 +589,25 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 
         const int row0 = m0 + wm * G::WROWS;
         const int col0 = n0 + wn * G::WCOLS;
+        // CONV epilogues: quad partials red[WMc][BN / 4] (sum, sum of squares over each wave's rows) -> the tile's contribution to
+        // the consumer's GroupNorm, partial[(sample, 256-pixel chunk)][group]: the layout of the separate statistics kernel
+        // (tld_vae.hip).  Needs one whole tile per chunk (gn_hw % 256 == 0, M % 256 == 0), N % BN == 0 and gn_cpg % 4 == 0.
+        auto gn_combine = [&](const float2* red) {
+            if constexpr (CONV) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const int tid = wid * 64 + lane;
+                const int qpg = p.gn_cpg >> 2;                       // quads per group
+                if (tid < BN / p.gn_cpg) {
+                    float a = 0.f, a2 = 0.f;
+                    for (int w2 = 0; w2 < G::WMc; ++w2)
+                        for (int k2 = 0; k2 < qpg; ++k2) { const float2 t = red[w2 * (BN / 4) + tid * qpg + k2]; a += t.x; a2 += t.y; }
+                    const int bb = m0 / p.gn_hw;
+                    const int chunk = (m0 - bb * p.gn_hw) >> 8, nchunk = p.gn_hw >> 8;
+                    p.gn_partial[((size_t)bb * nchunk + chunk) * p.gn_groups + n0 / p.gn_cpg + tid] = make_float2(a, a2);
+                }
+            }
+        };
         if constexpr (EPI == EPI_F32) {
 #pragma unroll
             for (int i = 0; i < G::TM; ++i)
@@ -883,6 +902,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 if (has_next) issue(m0n, n0n, g);
             } else if constexpr (EPI == EPI_BIAS_RESID) {
                 constexpr int P = 32 * 4 + 16;      // one 32x32 fp32 tile, padded pitch
+                float gsum[CONV ? G::TN : 1], gsq[CONV ? G::TN : 1];     // CONV: GroupNorm partials of this lane's column quad (lane & 7) per 32-column block
+                if constexpr (CONV) {
+#pragma unroll
+                    for (int j = 0; j < G::TN; ++j) { gsum[j] = 0.f; gsq[j] = 0.f; }
+                }
 #pragma unroll
                 for (int i = 0; i < G::TM; ++i) {
                     float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};   // row partials of the new residual
@@ -909,6 +933,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                 float4 o = rs_load4(px);
                                 o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
                                 rs_store4(px, o);
+                                if constexpr (CONV) {
+                                    const float r0 = rs_round(o.x), r1 = rs_round(o.y), r2 = rs_round(o.z), r3 = rs_round(o.w);
+                                    gsum[j] += (r0 + r1) + (r2 + r3);
+                                    gsq[j] = fmaf(r0, r0, fmaf(r1, r1, fmaf(r2, r2, fmaf(r3, r3, gsq[j]))));
+                                }
                                 if constexpr (G::WCOLS == 96) {          // (LayerNorm-1 fold: 96-column groups only)
                                     const float r0 = rs_round(o.x), r1 = rs_round(o.y), r2 = rs_round(o.z), r3 = rs_round(o.w);
                                     ps[itr] += (r0 + r1) + (r2 + r3);
@@ -931,6 +960,20 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                 if ((lane & 7) == 0 && row < p.M && slot < kLnSlots) p.stats_out[(size_t)row * kLnSlots + slot] = make_float2(a, q2);
                             }
                         }
+                    }
+                }
+                if constexpr (CONV) {
+                    if (p.gn_partial) {
+                        // lanes with the same (lane & 7) hold the same column quad for different rows: three xor steps (8, 16, 32)
+                        float2* red = reinterpret_cast<float2*>(smem + ((g - 1) & 1) * G::STAGE_BYTES + 8 * G::SCRATCH);       // [WMc][BN / 4]
+#pragma unroll
+                        for (int j = 0; j < G::TN; ++j) {
+                            float a = gsum[j], a2 = gsq[j];
+#pragma unroll
+                            for (int o2 = 8; o2 < 64; o2 <<= 1) { a += __shfl_xor(a, o2, 64); a2 += __shfl_xor(a2, o2, 64); }
+                            if (lane < 8) red[wm * (BN / 4) + wn * (G::WCOLS / 4) + j * 8 + lane] = make_float2(a, a2);
+                        }
+                        gn_combine(red);
                     }
                 }
             } else if constexpr (G::WCOLS == 64) {
@@ -988,6 +1031,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 if (!to_vt) {
                     // one 32-row x 64-col bf16 slab per pass: 128-B pitch, 16-B chunks XOR-swizzled with (row & 7)
                     constexpr int P = 128;
+                    // CONV: GroupNorm statistics of the tile for the consumer (GemmParams::gn_partial): per lane, (sum, sum of squares)
+                    // of the STORED values of its rows, one pair per 4-column quad (j, rq)
+                    float gsum[CONV ? G::TN * 4 : 1], gsq[CONV ? G::TN * 4 : 1];
+                    if constexpr (CONV) {
+#pragma unroll
+                        for (int q4 = 0; q4 < G::TN * 4; ++q4) { gsum[q4] = 0.f; gsq[q4] = 0.f; }
+                    }
 #pragma unroll
                     for (int i = 0; i < G::TM; ++i) {
 #pragma unroll
@@ -1015,6 +1065,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                 pk[2] = (bf16)fmaf(rs_, acc[i][j][rq * 4 + 2], bv.z);
                                 pk[3] = (bf16)fmaf(rs_, acc[i][j][rq * 4 + 3], bv.w);
                                 *reinterpret_cast<bf16x4*>(ws + e_l31 * P + ((((cl >> 3) ^ (e_l31 & 7)) << 4) | ((cl & 7) << 1))) = pk;
+                                if constexpr (CONV) {
+                                    const float f0 = (float)pk[0], f1 = (float)pk[1], f2 = (float)pk[2], f3 = (float)pk[3];
+                                    gsum[j * 4 + rq] += (f0 + f1) + (f2 + f3);
+                                    gsq[j * 4 + rq] = fmaf(f0, f0, fmaf(f1, f1, fmaf(f2, f2, fmaf(f3, f3, gsq[j * 4 + rq]))));
+                                }
                             }
 #pragma unroll
                         for (int itr = 0; itr < 4; ++itr) {
@@ -1027,6 +1082,18 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                 if constexpr (IS_QKV) *dst = v;              // attention re-reads q|k from L2
                                 else TLD_STORE(dst, v);
                             }
+                        }
+                    }
+                    if constexpr (CONV) {
+                        if (p.gn_partial) {
+                            // the 32 lanes of a half-wave are the rows of quad (j, rq, hi): one half_sum each, lane 0 / 32 files it
+                            float2* red = reinterpret_cast<float2*>(smem + ((g - 1) & 1) * G::STAGE_BYTES + 8 * G::SCRATCH);   // [WMc][BN / 4]
+#pragma unroll
+                            for (int q4 = 0; q4 < G::TN * 4; ++q4) {
+                                const float a = half_sum(gsum[q4]), a2 = half_sum(gsq[q4]);
+                                if (e_l31 == 0) red[wm * (BN / 4) + wn * (G::WCOLS / 4) + (q4 >> 2) * 8 + (q4 & 3) * 2 + e_hi] = make_float2(a, a2);
+                            }
+                            gn_combine(red);
                         }
                     }
                 } else {

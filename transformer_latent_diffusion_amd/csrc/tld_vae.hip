@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -294,6 +295,10 @@ struct tld_vae {
     hipEvent_t fork_ev = nullptr, join_ev[kAttnStreams] = {};
     float* out_f32 = nullptr;
 
+    // GroupNorm statistics fused into the producing convolution's epilogue: true while gn_partial describes the tensor the
+    // next group_norm() normalises (set by conv3x3, consumed / invalidated by group_norm and by anything else that writes x)
+    bool have_partial = false;
+    bool fuse_stats = true;               // TLD_VAE_FUSE_STATS=0: always the separate statistics kernel (A/B testing)
     bool debug = false;
     std::vector<Stage> stages;
     bool profile = false;
@@ -419,7 +424,9 @@ int group_norm(tld_vae* v, int src, int dst, const GnW& gn, int B, int HW, int C
     const int nchunk = (HW + ppb - 1) / ppb;
     const int TPP = C / 8, PPI = 256 / TPP;
     const size_t lds = (size_t)(PPI * C + C) * sizeof(float2);
-    hipLaunchKernelGGL(vae_gn_stats_kernel, dim3(nchunk, B), dim3(256), lds, s, v->data(src), HW, C, v->G, ppb, v->gn_partial);
+    if (!v->have_partial)
+        hipLaunchKernelGGL(vae_gn_stats_kernel, dim3(nchunk, B), dim3(256), lds, s, v->data(src), HW, C, v->G, ppb, v->gn_partial);
+    v->have_partial = false;
     hipLaunchKernelGGL(vae_gn_finalize_kernel, dim3(B), dim3(v->G * 8), 0, s, v->gn_partial, nchunk, v->G,
                        1.0 / ((double)HW * (C / v->G)), kGnEps, v->gn_stats);
     if (silu) hipLaunchKernelGGL(vae_gn_apply_kernel<true>, dim3(nchunk, B), dim3(256), 0, s, v->data(src), v->gn_stats, gn.g, gn.b, v->data(dst), HW, C, v->G, ppb);
@@ -441,6 +448,14 @@ int conv3x3(tld_vae* v, int src, int dst, const ConvW& cw, int B, int H, int W, 
     if (epi == EPI_BIAS_BF16) { p.out_bf16 = v->data(dst); p.ldo = cw.cout; }
     else if (epi == EPI_BIAS_RESID) { p.resid = reinterpret_cast<resid_t*>(v->data(dst)); p.ldr = cw.cout; }
     else { p.c_f32 = c_f32; p.ldc = cw.cout; }
+    // the consumer of a bf16 conv output is always a GroupNorm: leave its per-chunk statistics behind when the shapes allow
+    // (a 256-row tile = one 256-pixel chunk of one sample; whole column tiles; groups made of whole 4-column quads)
+    const int cpg = cw.cout / v->G;
+    v->have_partial = false;
+    if (v->fuse_stats && epi != EPI_F32 && (H * W) % 256 == 0 && cw.cout % 128 == 0 && cpg % 4 == 0 && cw.cout % cpg == 0) {
+        p.gn_partial = v->gn_partial; p.gn_groups = v->G; p.gn_cpg = cpg; p.gn_hw = H * W;
+        v->have_partial = true;
+    }
     launch_gemm(p, epi, s);
     return check_launch("conv3x3");
 }
@@ -530,6 +545,7 @@ int attention(tld_vae* v, int* xi, int B, int H, int W, int C, hipStream_t s) {
             HIP_TRY(hipStreamWaitEvent(s, v->join_ev[i], 0));
         }
     if (int rc = gemm(v, v->data(t), C, v->attn_out.w, C, M, C, C, EPI_BIAS_RESID, v->attn_out.b, v->data(x), C, nullptr, s)) return rc;
+    v->have_partial = false;               // x changed: the statistics a convolution left behind are stale
     return check_launch("attention");
 }
 
@@ -581,6 +597,7 @@ int tld_vae_create(const tld_vae_config* cfg, tld_vae** out) {
     v->G = cfg->norm_num_groups; v->zc = cfg->latent_channels; v->oc = cfg->out_channels; v->nb = cfg->n_blocks; v->hl = cfg->latent_size;
     v->boc.assign(cfg->block_out_channels, cfg->block_out_channels + cfg->n_blocks);
     v->C0 = v->boc[v->nb - 1];
+    v->fuse_stats = !(getenv("TLD_VAE_FUSE_STATS") && atoi(getenv("TLD_VAE_FUSE_STATS")) == 0);
     v->buf_elems = max_act_elems(v) * (size_t)cfg->max_batch;
     const size_t bytes = v->buf_elems * 2 + kHdr;
     if (bytes >= (1ull << 32)) {
@@ -723,6 +740,7 @@ int tld_vae_decode(tld_vae* v, const void* z, float* out, int32_t batch, int32_t
     for (int k = 0; k < VC_COUNT; ++k) if (!v->profile) v->ev_used[k] = 0;
 
     int H = v->hl, W = v->hl;
+    v->have_partial = false;
     const float* zf = reinterpret_cast<const float*>(z);
     {
         Timer t(v, VC_OTHER, s);
