@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--gemm-dtype", default="bf16", choices=("bf16", "fp8"),
                     help="operand type of the QKV / MLP GEMMs: bf16 (headline) or fp8 (MX-fp8, BASELINE config C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-vae", action="store_true",
+                    help="after the timed region, also decode each rank's latents with the native VAE (SDXL-VAE geometry, random-init "
+                         "weights) and report it beside the headline line ('with_vae'); never part of 'value'")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of the GEMM classes")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-device", action="store_true",
@@ -267,6 +270,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    vae_info = None
+    if args.with_vae:
+        from transformer_latent_diffusion_amd.vae import AutoencoderKLDecoder, VaeDecoderConfig
+        per_sample = (8 * S) ** 2 * 256 * 2                     # largest activation of the decoder, bytes per sample
+        vae = AutoencoderKLDecoder(VaeDecoderConfig(), max_batch=max(1, min(B, int(3.9 * 2 ** 30 // per_sample)))).to(dev)
+        lat = (out[rank * B:(rank + 1) * B] * 8).float()        # scale_factor 8 (tld/diffusion.py:91,180)
+        img = vae.decode(lat)[0]
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            img = vae.decode(lat)[0]
+        fence()
+        vdt = (time.perf_counter() - t1) / args.steps
+        assert torch.isfinite(img).all()
+        vae_info = {"vae_ms_per_batch": vdt * 1e3, "vae_images_per_sec_per_gpu": B / vdt,
+                    "end_to_end_images_per_sec": total / (dt / args.steps + vdt),
+                    "note": "denoise + native VAE decode (tools/vae_bench.py, DESIGN.md 7.1) back to back on each rank's shard; "
+                            "SDXL-VAE geometry with random-init weights (no checkpoint offline); not part of 'value'"}
+
     prof = {}
     if not args.no_profile:
         prof = dict(warm_prof)                       # untimed pass: all classes (context for the JSON)
@@ -317,6 +339,8 @@ def main():
                         "flops_per_launch is the average over a forward's launches (block 0 runs on the un-doubled batch)",
                 "mfma_aggregate_tflops": tot_f / tot_t / 1e12,
             }
+        if vae_info:
+            line["with_vae"] = vae_info
         if world == 1 and not args.no_cpu_baseline and S == 32:
             line["cpu_baseline"] = cpu_baseline(cfg, sd)
         print(json.dumps(line), flush=True)

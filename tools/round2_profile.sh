@@ -8,6 +8,7 @@ timeout 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "tests
 bash tools/pmc_traffic.sh $O/pmc > $O/pmc.log 2>&1; tail -6 $O/pmc.log
 cp $O/pmc/traffic.json profiles/r02_pmc_traffic.json 2>/dev/null
 timeout 900 python bench.py --steps 5 --warmup 2 > $O/bench_c1.json 2> $O/bench_c1.err; cut -c1-300 $O/bench_c1.json
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --with-vae > $O/bench_c1_with_vae.json 2> $O/bench_c1_with_vae.err; grep -o '"with_vae".*' $O/bench_c1_with_vae.json | cut -c1-300
 timeout 300 python bench.py --image-size 64 --images-per-gpu 16 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err; cut -c1-200 $O/bench_c3.json
 timeout 300 python bench.py --image-size 128 --images-per-gpu 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c4_bf16.json 2> $O/bench_c4_bf16.err; cut -c1-200 $O/bench_c4_bf16.json
 timeout 300 python bench.py --image-size 128 --images-per-gpu 4 --steps 2 --warmup 1 --no-cpu-baseline --gemm-dtype fp8 > $O/bench_c4_fp8.json 2> $O/bench_c4_fp8.err; cut -c1-200 $O/bench_c4_fp8.json

@@ -11,7 +11,8 @@
 #include <type_traits>
 
 // -DTLD_DBG_EPI builds honour GemmParams::dbg_epi in the fused depthwise epilogue (cost attribution):
-//   1 = no global stores, 2 = identity instead of GELU, 4 = skip the conv phase, 8 = skip the LDS image write too
+//   1 = no global stores, 2 = identity instead of GELU, 4 = skip the conv phase, 8 = skip the LDS image write too,
+//   16 = (residual-add epilogue) no read of the residual either
 #ifdef TLD_DBG_EPI
 #define TLD_EPI_BIT(b) ((p.dbg_epi & (b)) != 0)
 #else
@@ -930,9 +931,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             const int row = row0 + i * 32 + rl, col = col0 + j * 32 + ch * 4;
                             if (row < p.M && col < p.N) {
                                 resid_t* px = p.resid + (size_t)row * p.ldr + col;
-                                float4 o = rs_load4(px);
+                                float4 o = TLD_EPI_BIT(16) ? make_float4(0.f, 0.f, 0.f, 0.f) : rs_load4(px);      // (attribution builds only)
                                 o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-                                rs_store4(px, o);
+                                if (!TLD_EPI_BIT(1)) rs_store4(px, o);
                                 if constexpr (CONV) {
                                     const float r0 = rs_round(o.x), r1 = rs_round(o.y), r2 = rs_round(o.z), r3 = rs_round(o.w);
                                     gsum[j] += (r0 + r1) + (r2 + r3);
