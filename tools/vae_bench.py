@@ -19,8 +19,8 @@ sys.path.insert(0, REPO)
 from transformer_latent_diffusion_amd.vae import AutoencoderKLDecoder, VaeDecoderConfig, vae_decoder_spec  # noqa: E402
 
 
-def decode_flops(cfg: VaeDecoderConfig, latent: int) -> float:
-    """2 * MACs per image of AutoencoderKL.decode."""
+def decode_flops(cfg: VaeDecoderConfig, latent: int, only_conv3x3: bool = False) -> float:
+    """2 * MACs per image of AutoencoderKL.decode (only_conv3x3: the implicit-GEMM 3x3 convolutions, conv_out included)."""
     spec = vae_decoder_spec(cfg)
     boc = list(cfg.block_out_channels)
     res = {}                                   # key prefix -> H at which the layer runs
@@ -28,6 +28,8 @@ def decode_flops(cfg: VaeDecoderConfig, latent: int) -> float:
     fl = 0.0
     def conv(key, hh):
         co, ci, k, _ = spec[key + ".weight"]
+        if only_conv3x3 and (k != 3 or ci < 64):
+            return 0.0
         return 2.0 * hh * hh * co * ci * k * k
     if cfg.use_post_quant_conv:
         fl += conv("post_quant_conv", h)
@@ -35,7 +37,7 @@ def decode_flops(cfg: VaeDecoderConfig, latent: int) -> float:
     c0 = boc[-1]
     for r in ("decoder.mid_block.resnets.0", "decoder.mid_block.resnets.1"):
         fl += conv(r + ".conv1", h) + conv(r + ".conv2", h)
-    if cfg.mid_block_add_attention:
+    if cfg.mid_block_add_attention and not only_conv3x3:
         n = h * h
         fl += 4 * 2.0 * n * c0 * c0 + 2 * 2.0 * n * n * c0
     for i in range(len(boc)):
@@ -80,6 +82,14 @@ def main():
            "frac_of_bf16_mfma_peak": a.batch * fl / dt / 2.5e15, "dtype": "bf16", "data": "synthetic (random-init weights)",
            "classes_ms": {k: round(v[0], 3) for k, v in prof.items()}, "classes_launches": {k: v[1] for k, v in prof.items()},
            "finite": bool(torch.isfinite(img).all())}
+    cfl = decode_flops(cfg, a.latent, only_conv3x3=True) * a.batch
+    cms, cn = prof["conv3x3"]
+    if cms > 0:
+        # dominant kernel class: the implicit-GEMM 3x3 convolutions (gemm256p_kernel<.., CONV>), HIP events on the launch stream
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm256p_kernel<BN, EPI, false, CONV=true> (all 3x3 convolutions of one decode)",
+                           "achieved": cfl / (cms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": cfl / (cms * 1e-3) / 1e12 / 2500.0,
+                           "launches": cn, "flops": cfl, "total_ms": cms,
+                           "traffic": None, "traffic_source": "see profiles/r02_vae_pmc.json (separate PMC passes)"}
     if a.cpu_sample:
         from oracle.vae_ref import TorchRefVaeDecoder
         ref = TorchRefVaeDecoder(cfg, vae.state_dict())
