@@ -194,6 +194,40 @@ TLD_API int tld_debug_conv3x3(const void* in_bf16, const void* w_bf16, float* ou
 TLD_API int64_t tld_vae_weight_bytes(const tld_vae* v);
 TLD_API int tld_vae_destroy(tld_vae* v);
 
+/* ---- CLIP text tower: the front edge ---------------------------------------------------
+ * Replaces `model.encode_text(text_tokens)` in encode_text, tld/diffusion.py:136-140, where `model` is OpenAI CLIP
+ * "ViT-L/14" from `clip.load` (tld/diffusion.py:160, tld/configs.py:46-48; third-party, not in the reference checkout).
+ * Restated: CLIP.encode_text of openai/CLIP clip/model.py (token + positional embedding, pre-LN residual blocks with
+ * causal nn.MultiheadAttention and a QuickGELU MLP, ln_final, the EOT token's row times text_projection).  Tokenisation
+ * stays on the host (clip.tokenize); the engine takes token ids. */
+typedef struct tld_clip tld_clip;
+
+typedef struct tld_clip_config {
+    int32_t vocab_size;         /* 49408 */
+    int32_t context_length;     /* 77 (<= 128) */
+    int32_t width;              /* 768: transformer width, multiple of 64 */
+    int32_t heads;              /* width / 64 */
+    int32_t layers;             /* 12 */
+    int32_t embed_dim;          /* 768: columns of text_projection */
+    int32_t max_batch;
+    int32_t device_id;
+} tld_clip_config;
+
+TLD_API int tld_clip_create(const tld_clip_config* cfg, tld_clip** out);
+/* CLIP.state_dict() entries, one at a time (host fp32): "token_embedding.weight", "positional_embedding", "text_projection",
+ * "ln_final.*", "transformer.resblocks.<i>.{ln_1,ln_2}.*", ".attn.in_proj_{weight,bias}", ".attn.out_proj.*", ".mlp.c_fc.*",
+ * ".mlp.c_proj.*".  "visual.*", "logit_scale" and the archive's metadata entries are accepted and ignored. */
+TLD_API int tld_clip_load_tensor(tld_clip* c, const char* key, const void* host_ptr, const int64_t* shape, int32_t ndim, int32_t dtype);
+TLD_API int tld_clip_finalize_weights(tld_clip* c);
+/* CLIP.encode_text(text):  tokens [batch, context_length] int32 (device), eot_index [batch] int32 (device) = text.argmax(-1)
+ * (the EOT token has the largest id), out [batch, embed_dim] fp32 (device). */
+TLD_API int tld_clip_encode_text(tld_clip* c, const int32_t* tokens, const int32_t* eot_index, float* out, int32_t batch, void* hip_stream);
+/* Test hook: copy a workspace buffer of the LAST encode_text to host fp32 (synchronises): "x", "tmp" ([T, width] fp32), "pooled"
+ * ([batch, width]), "h", "att" ([T, width]), "qkv" ([T, 3 width]), "f" ([T, 4 width]) -- the state after the last block. */
+TLD_API int tld_clip_read_buffer(tld_clip* c, const char* name, float* host_out, int64_t numel);
+TLD_API int64_t tld_clip_weight_bytes(const tld_clip* c);
+TLD_API int tld_clip_destroy(tld_clip* c);
+
 TLD_API const char* tld_last_error(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,94 @@
+"""GPU: the CLIP text tower through the C ABI (tld_clip_*), against the fp32 restatement of
+openai/CLIP's encode_text (oracle/clip_ref.py; parity unpinned against the clip package itself, see its header).
+Tolerance: bf16 projection operands with fp32 residual stream / LayerNorm / softmax -- CLIP_TOL rel-rms on the [B, 768] output, the
+denoiser's own forward tolerance (the reference runs this tower in fp16, tld/configs.py:48; the MFMA GEMM here is bf16)."""
+import ctypes as C
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_rms
+from test_clip_host import TINY, _tokens
+from test_gpu_parity import _dev
+
+pytestmark = pytest.mark.gpu
+
+CLIP_TOL = 2e-2
+
+
+def _enc(cfg, seed, max_batch=8):
+    from transformer_latent_diffusion_amd.clip_text import ClipTextEncoder, synth_clip_state_dict
+    sd = synth_clip_state_dict(cfg, seed)
+    enc = ClipTextEncoder(cfg, max_batch=max_batch)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return sd, enc.to(_dev())
+
+
+def test_tiny_text_tower_against_the_oracle():
+    from oracle.clip_ref import TorchRefClipText
+    sd, enc = _enc(TINY, 3, max_batch=4)
+    text = _tokens(TINY, 11, 1)                                   # 11 > max_batch 4: chunked
+    want = TorchRefClipText(TINY, sd).encode_text(text)
+    got = enc.encode_text(text.to(_dev()))
+    assert got.shape == (11, 64) and got.dtype == torch.float32 and got.device.type == "cuda"
+    e = rel_rms(got.cpu().numpy(), want.numpy())
+    assert e < CLIP_TOL, e
+    again = enc.encode_text(text.to(_dev()).to(torch.int32))
+    assert torch.equal(got, again)                                # deterministic; int32 ids accepted
+    alone = enc.encode_text(text[5:6].to(_dev()))
+    assert torch.equal(alone[0], got[5])                          # batch independent
+
+
+def test_vit_l14_text_tower_against_the_oracle():
+    from oracle.clip_ref import TorchRefClipText
+    from transformer_latent_diffusion_amd.clip_text import ClipTextConfig
+    cfg = ClipTextConfig()
+    sd, enc = _enc(cfg, 0, max_batch=4)
+    text = _tokens(cfg, 4, 2)
+    want = TorchRefClipText(cfg, sd).encode_text(text)
+    got = enc.encode_text(text.to(_dev())).cpu()
+    e = rel_rms(got.numpy(), want.numpy())
+    print(f"clip ViT-L/14 text tower rel-rms {e:.2e}")
+    assert got.shape == (4, 768) and e < CLIP_TOL, e
+    assert enc.weight_bytes > 85_000_000 * 2                      # bf16 block weights + fp32 embeddings
+
+
+def test_pipeline_shell_keeps_labels_on_the_device():
+    """DiffusionTransformer(cfg, clip_model=ClipTextEncoder): encode_text stays on the GPU, the sampler consumes it."""
+    from transformer_latent_diffusion_amd import DenoiserConfig, DiffusionGenerator, Denoiser
+    from transformer_latent_diffusion_amd.clip_text import ClipTextConfig
+    cfg = ClipTextConfig(vocab_size=1000, context_length=16, width=128, heads=2, layers=2, embed_dim=768)
+    sd, enc = _enc(cfg, 4)
+    labels = enc.encode_text(_tokens(cfg, 2, 3).to(_dev()))
+    assert labels.shape == (2, 768) and labels.device.type == "cuda"
+    dcfg = DenoiserConfig(image_size=16, noise_embed_dims=128, patch_size=2, embed_dim=128, dropout=0, n_layers=2)
+    gen = DiffusionGenerator(Denoiser(**asdict(dcfg)).to(_dev()), None, _dev(), torch.float32)
+    _, lat = gen.generate(labels=labels, num_imgs=2, n_iter=3, class_guidance=3, img_size=16, seed=1)
+    assert lat.shape == (2, 4, 16, 16) and torch.isfinite(lat).all()
+
+
+def test_clip_abi_error_paths():
+    from transformer_latent_diffusion_amd import _lib
+    L = _lib.lib()
+    h = C.c_void_p()
+    cc = _lib.TldClipConfig(1000, 16, 128, 3, 2, 64, 2, 0)        # heads * 64 != width
+    assert L.tld_clip_create(C.byref(cc), C.byref(h)) == 1 and b"head_dim" in L.tld_last_error()
+    cc = _lib.TldClipConfig(1000, 200, 128, 2, 2, 64, 2, 0)       # context too long
+    assert L.tld_clip_create(C.byref(cc), C.byref(h)) == 1 and b"context_length" in L.tld_last_error()
+    cc = _lib.TldClipConfig(1000, 16, 128, 2, 2, 64, 2, 0)
+    assert L.tld_clip_create(C.byref(cc), C.byref(h)) == 0
+    tok = torch.zeros(1, 16, dtype=torch.int32, device=_dev())
+    eot = torch.zeros(1, dtype=torch.int32, device=_dev())
+    out = torch.zeros(1, 64, device=_dev())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L.tld_clip_encode_text(h, tok.data_ptr(), eot.data_ptr(), out.data_ptr(), 1, st) == 4          # not finalized
+    assert L.tld_clip_finalize_weights(h) == 4 and b"missing state_dict entry" in L.tld_last_error()
+    a = np.zeros((3, 3), np.float32)
+    shp = (C.c_int64 * 2)(3, 3)
+    assert L.tld_clip_load_tensor(h, b"nonsense", a.ctypes.data_as(C.c_void_p), shp, 2, 0) == 2
+    assert L.tld_clip_load_tensor(h, b"visual.proj", a.ctypes.data_as(C.c_void_p), shp, 2, 0) == 0           # ignored
+    assert L.tld_clip_load_tensor(h, b"token_embedding.weight", a.ctypes.data_as(C.c_void_p), shp, 2, 0) == 0
+    assert L.tld_clip_finalize_weights(h) == 3 and b"token_embedding.weight" in L.tld_last_error()
+    assert L.tld_clip_destroy(h) == 0

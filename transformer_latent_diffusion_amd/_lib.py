@@ -26,6 +26,8 @@ ABI_SYMBOLS = (
     "tld_vae_create", "tld_vae_load_tensor", "tld_vae_finalize_weights", "tld_vae_decode", "tld_vae_set_debug",
     "tld_vae_read_stage", "tld_vae_set_profile", "tld_vae_get_profile", "tld_debug_conv3x3", "tld_vae_weight_bytes",
     "tld_vae_destroy",
+    "tld_clip_create", "tld_clip_load_tensor", "tld_clip_finalize_weights", "tld_clip_encode_text", "tld_clip_read_buffer", "tld_clip_weight_bytes",
+    "tld_clip_destroy",
     "tld_last_error",
 )
 
@@ -43,6 +45,11 @@ class TldVaeConfig(C.Structure):
                 ("block_out_channels", C.c_int32 * 4), ("layers_per_block", C.c_int32), ("norm_num_groups", C.c_int32),
                 ("mid_block_attention", C.c_int32), ("use_post_quant_conv", C.c_int32), ("latent_size", C.c_int32),
                 ("max_batch", C.c_int32), ("device_id", C.c_int32)]
+
+
+class TldClipConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("vocab_size", "context_length", "width", "heads", "layers", "embed_dim", "max_batch",
+                                         "device_id")]
 
 
 _lib = None
@@ -102,8 +109,16 @@ def lib() -> C.CDLL:
     L.tld_vae_weight_bytes.argtypes = [vp]
     L.tld_vae_weight_bytes.restype = C.c_int64
     L.tld_vae_destroy.argtypes = [vp]
+    L.tld_clip_create.argtypes = [C.POINTER(TldClipConfig), C.POINTER(vp)]
+    L.tld_clip_load_tensor.argtypes = [vp, C.c_char_p, vp, i64p, i32, i32]
+    L.tld_clip_finalize_weights.argtypes = [vp]
+    L.tld_clip_encode_text.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.tld_clip_read_buffer.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_int64]
+    L.tld_clip_weight_bytes.argtypes = [vp]
+    L.tld_clip_weight_bytes.restype = C.c_int64
+    L.tld_clip_destroy.argtypes = [vp]
     for name in ABI_SYMBOLS:
-        if name not in ("tld_last_error", "tld_engine_weight_bytes", "tld_vae_weight_bytes"):
+        if name not in ("tld_last_error", "tld_engine_weight_bytes", "tld_vae_weight_bytes", "tld_clip_weight_bytes"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
