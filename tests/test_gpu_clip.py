@@ -92,3 +92,32 @@ def test_clip_abi_error_paths():
     assert L.tld_clip_load_tensor(h, b"token_embedding.weight", a.ctypes.data_as(C.c_void_p), shp, 2, 0) == 0
     assert L.tld_clip_finalize_weights(h) == 3 and b"token_embedding.weight" in L.tld_last_error()
     assert L.tld_clip_destroy(h) == 0
+
+
+def test_text_to_image_all_native():
+    """The reference's whole inference pipeline with every model native: prompt -> (stub tokeniser) -> ClipTextEncoder -> denoiser
+    engine -> AutoencoderKLDecoder -> PIL image (tld/diffusion.py:165-186); only the BPE tokeniser is a stand-in (no vocabulary file
+    offline).  Same prompt and seed -> same picture; another prompt -> another picture."""
+    from PIL import Image
+    from transformer_latent_diffusion_amd import (AutoencoderKLDecoder, DenoiserConfig, DiffusionTransformer, LTDConfig, VaeDecoderConfig)
+    from transformer_latent_diffusion_amd.clip_text import ClipTextConfig, ClipTextEncoder
+    ccfg = ClipTextConfig(vocab_size=1000, context_length=16, width=128, heads=2, layers=2, embed_dim=768)
+    enc = ClipTextEncoder(ccfg, init_seed=1).to(_dev())
+    vae = AutoencoderKLDecoder(VaeDecoderConfig(block_out_channels=(64, 128), layers_per_block=1), init_seed=2).to(_dev())
+
+    def tokenize(prompts):                               # clip.tokenize stand-in: SOT, one id per character, EOT, zero padding
+        t = torch.zeros(len(prompts), ccfg.context_length, dtype=torch.long)
+        for i, p in enumerate(prompts):
+            ids = [1 + (ord(ch) % 900) for ch in p][: ccfg.context_length - 2]
+            t[i, 0] = ccfg.vocab_size - 2
+            t[i, 1:1 + len(ids)] = torch.tensor(ids)
+            t[i, 1 + len(ids)] = ccfg.vocab_size - 1
+        return t
+
+    pipe = DiffusionTransformer(LTDConfig(denoiser_cfg=DenoiserConfig(n_channels=4)), vae=vae,
+                                text_encoder=lambda prompts: enc.encode_text(tokenize(prompts).to(_dev())), run_device=_dev())
+    a = pipe.generate_image_from_text(prompt="a cute cat", seed=3, n_iter=4)
+    assert isinstance(a, Image.Image) and a.size == (32, 32) and a.mode == "RGB"            # 16 x 16 latents, two-level decoder: 2x
+    b = pipe.generate_image_from_text(prompt="a cute cat", seed=3, n_iter=4)
+    c = pipe.generate_image_from_text(prompt="a red car", seed=3, n_iter=4)
+    assert np.array_equal(np.asarray(a), np.asarray(b)) and not np.array_equal(np.asarray(a), np.asarray(c))
