@@ -284,7 +284,17 @@ def main():
         fence()
         vdt = (time.perf_counter() - t1) / args.steps
         assert torch.isfinite(img).all()
-        vae_info = {"vae_ms_per_batch": vdt * 1e3, "vae_images_per_sec_per_gpu": B / vdt,
+        vae_cpu = None
+        if world == 1 and not args.no_cpu_baseline:             # cpu_baseline leg of the VAE stage: fp32 torch restatement, one image
+            from oracle.vae_ref import TorchRefVaeDecoder
+            ref = TorchRefVaeDecoder(VaeDecoderConfig(), vae.state_dict())
+            zc = lat[:1].cpu()
+            ref.decode(zc)
+            t2 = time.perf_counter()
+            ref.decode(zc)
+            vae_cpu = {"value": 1.0 / (time.perf_counter() - t2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                       "sample": "1 image, fp32 torch restatement of AutoencoderKL.decode (oracle/vae_ref.py)"}
+        vae_info = {"vae_ms_per_batch": vdt * 1e3, "vae_images_per_sec_per_gpu": B / vdt, "vae_cpu_baseline": vae_cpu,
                     "end_to_end_images_per_sec": total / (dt / args.steps + vdt),
                     "note": "denoise + native VAE decode (tools/vae_bench.py, DESIGN.md 7.1) back to back on each rank's shard; "
                             "SDXL-VAE geometry with random-init weights (no checkpoint offline); not part of 'value'"}

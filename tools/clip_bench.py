@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""CLIP ViT-L/14 text tower on one GPU: prompts/s of the native encoder (random-init weights), optional CPU leg.
+"""CLIP ViT-L/14 text tower on one GPU: prompts/s of the native encoder (random-init weights).
 
-    python tools/clip_bench.py [--batch 64] [--iters 10] [--cpu-sample 4]"""
+    python tools/clip_bench.py [--batch 64] [--iters 10]"""
 import argparse, json, os, sys, time
 import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,7 +12,6 @@ from test_clip_host import _tokens                                              
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--iters", type=int, default=10)
-ap.add_argument("--cpu-sample", type=int, default=0)
 a = ap.parse_args()
 cfg = ClipTextConfig()
 enc = ClipTextEncoder(cfg, max_batch=a.batch).to("cuda")
@@ -29,12 +28,4 @@ flops = a.batch * n * L * (2 * w * 3 * w + 2 * w * w + 2 * 2 * w * 4 * w) + a.ba
 line = {"metric": "clip_text_prompts_per_sec", "value": a.batch / dt, "unit": "prompts/s", "batch": a.batch, "ms_per_batch": dt * 1e3,
         "gflop_per_prompt": flops / a.batch / 1e9, "tflops": flops / dt / 1e12, "dtype": "bf16 GEMM operands, fp32 residual / LayerNorm / softmax",
         "data": "synthetic (random-init weights)", "finite": bool(torch.isfinite(out).all())}
-if a.cpu_sample:
-    from oracle.clip_ref import TorchRefClipText
-    ref = TorchRefClipText(cfg, enc.state_dict())
-    tc = text[:a.cpu_sample].cpu()
-    ref.encode_text(tc[:1])
-    t0 = time.perf_counter(); ref.encode_text(tc); ct = time.perf_counter() - t0
-    line["cpu_baseline"] = {"value": a.cpu_sample / ct, "unit": "prompts/s", "cores": torch.get_num_threads(), "kind": "port",
-                            "sample": f"{a.cpu_sample} prompt(s), fp32 torch restatement (oracle/clip_ref.py)"}
 print(json.dumps(line))

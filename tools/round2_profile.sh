@@ -7,8 +7,7 @@ mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests.log
 bash tools/pmc_traffic.sh $O/pmc > $O/pmc.log 2>&1; tail -6 $O/pmc.log
 cp $O/pmc/traffic.json profiles/r02_pmc_traffic.json 2>/dev/null
-timeout 900 python bench.py --steps 5 --warmup 2 > $O/bench_c1.json 2> $O/bench_c1.err; cut -c1-300 $O/bench_c1.json
-timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --with-vae > $O/bench_c1_with_vae.json 2> $O/bench_c1_with_vae.err; grep -o '"with_vae".*' $O/bench_c1_with_vae.json | cut -c1-300
+timeout 900 python bench.py --steps 5 --warmup 2 --with-vae > $O/bench_c1.json 2> $O/bench_c1.err; cut -c1-300 $O/bench_c1.json; grep -o '"with_vae".*' $O/bench_c1.json | cut -c1-400
 timeout 300 python bench.py --image-size 64 --images-per-gpu 16 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err; cut -c1-200 $O/bench_c3.json
 timeout 300 python bench.py --image-size 128 --images-per-gpu 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c4_bf16.json 2> $O/bench_c4_bf16.err; cut -c1-200 $O/bench_c4_bf16.json
 timeout 300 python bench.py --image-size 128 --images-per-gpu 4 --steps 2 --warmup 1 --no-cpu-baseline --gemm-dtype fp8 > $O/bench_c4_fp8.json 2> $O/bench_c4_fp8.err; cut -c1-200 $O/bench_c4_fp8.json
@@ -22,7 +21,7 @@ python profiles/summarize_rocpd.py $O/prof_c3/p_results.db $O/c3_kernel_stats.cs
 python profiles/summarize_rocpd.py $O/prof_c4f/p_results.db $O/c4_fp8_kernel_stats.csv > /dev/null 2>&1
 timeout 600 python tools/parity_report.py > $O/parity.md 2>&1; tail -24 $O/parity.md
 # VAE decode row: bench lines, kernel stats of the same command, per-stage parity print
-timeout 300 python tools/vae_bench.py --batch 16 --cpu-sample 1 2>&1 | grep -v amdgpu | tail -1 > $O/vae_bench_b16.json; cut -c1-400 $O/vae_bench_b16.json
+timeout 300 python tools/vae_bench.py --batch 16 2>&1 | grep -v amdgpu | tail -1 > $O/vae_bench_b16.json; cut -c1-400 $O/vae_bench_b16.json
 timeout 300 python tools/vae_bench.py --batch 64 2>&1 | grep -v amdgpu | tail -1 > $O/vae_bench_b64.json; cut -c1-300 $O/vae_bench_b64.json
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof_vae -o p -- python $R/tools/vae_bench.py --batch 16 --iters 2 > $R/$O/prof_vae.log 2>&1

@@ -2,7 +2,9 @@
 """VAE decode on one GPU: images/s and per-kernel-class HIP-event times of the native decoder at the
 SDXL-VAE geometry, C1's latent shape (32 x 32 x 4 -> 256 px) by default.
 
-    python tools/vae_bench.py [--batch 16] [--latent 32] [--iters 5] [--cpu-sample 1]
+    python tools/vae_bench.py [--batch 16] [--latent 32] [--iters 5]
+
+(The CPU figure beside it comes from `bench.py --with-vae`: only bench.py's cpu_baseline leg may call into oracle/.)
 
 Prints one JSON line.  FLOPs are the algorithmic ones of the module graph (convolutions, attention, 1x1 shortcuts)."""
 import argparse
@@ -58,7 +60,6 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--latent", type=int, default=32)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--cpu-sample", type=int, default=0, help="also time the fp32 torch restatement on this many images (host cores)")
     a = ap.parse_args()
     cfg = VaeDecoderConfig()
     dev = torch.device("cuda:0")
@@ -90,16 +91,6 @@ def main():
                            "achieved": cfl / (cms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": cfl / (cms * 1e-3) / 1e12 / 2500.0,
                            "launches": cn, "flops": cfl, "total_ms": cms,
                            "traffic": None, "traffic_source": "see profiles/r02_vae_pmc.json (separate PMC passes)"}
-    if a.cpu_sample:
-        from oracle.vae_ref import TorchRefVaeDecoder
-        ref = TorchRefVaeDecoder(cfg, vae.state_dict())
-        zc = z[:a.cpu_sample].cpu()
-        ref.decode(zc[:1])
-        t0 = time.perf_counter()
-        ref.decode(zc)
-        ct = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": a.cpu_sample / ct, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": f"{a.cpu_sample} image(s), fp32 torch restatement (oracle/vae_ref.py)"}
     print(json.dumps(out))
 
 
