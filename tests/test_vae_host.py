@@ -197,3 +197,12 @@ def test_load_vae_checkpoint_reads_a_diffusers_directory(tmp_path):
     assert cfg2 is None and set(got2) == set(got)
     with pytest.raises(FileNotFoundError):
         load_vae_checkpoint(str(tmp_path))
+
+
+def test_engine_batch_limit_follows_the_4gib_buffer_rule():
+    from transformer_latent_diffusion_amd.vae import engine_batch_limit, max_activation_elems
+    sdxl = VaeDecoderConfig()
+    assert max_activation_elems(sdxl, 32) == 256 * 256 * 256              # the upsampled 256-channel image at 256 px
+    assert engine_batch_limit(sdxl, 32) == 127                             # max_batch <= 127 at 256 px
+    assert engine_batch_limit(sdxl, 64) == 31 and engine_batch_limit(sdxl, 128) == 7
+    assert max_activation_elems(TINY, 8) == max(8 * 8 * 128 * 3, 16 * 16 * 128)

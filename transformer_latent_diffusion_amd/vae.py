@@ -112,6 +112,26 @@ def synth_vae_state_dict(cfg: VaeDecoderConfig, seed: int = 0) -> "OrderedDict[s
     return out
 
 
+def max_activation_elems(cfg: VaeDecoderConfig, latent_size: int) -> int:
+    """Elements per sample of the decoder's largest activation (what sizes the engine's four ping-pong buffers; mirrors
+    max_act_elems in csrc/tld_vae.hip)."""
+    boc = list(cfg.block_out_channels)
+    h, c = latent_size, boc[-1]
+    mx = h * h * c * 3                                   # attention q | k | v
+    for i, cout in enumerate(reversed(boc)):
+        mx = max(mx, h * h * max(c, cout))
+        c = cout
+        if i != len(boc) - 1:
+            h *= 2
+            mx = max(mx, h * h * c)
+    return mx
+
+
+def engine_batch_limit(cfg: VaeDecoderConfig, latent_size: int) -> int:
+    """Largest per-call batch the engine accepts at this resolution: one bf16 activation buffer (+ its 2-KiB zero page) < 4 GiB."""
+    return int(((1 << 32) - 2048 - 1) // (2 * max_activation_elems(cfg, latent_size)))
+
+
 _OLD_ATTN = ((".query.", ".to_q."), (".key.", ".to_k."), (".value.", ".to_v."), (".proj_attn.", ".to_out.0."))
 
 
@@ -235,7 +255,9 @@ class AutoencoderKLDecoder:
     def _ensure_engine(self, device: torch.device, latent_size: int, batch: int):
         if device.type != "cuda":
             raise RuntimeError("AutoencoderKLDecoder.decode needs a HIP device (tensors on 'cuda'); there is no CPU path")
-        nb = self.max_batch                       # (sized once: a smaller first batch must not rebuild the engine later)
+        # (sized once: a smaller first batch must not rebuild the engine later.)  One activation buffer must stay below 4 GiB
+        # (32-bit DMA offsets): at large resolutions the engine decodes fewer samples per call than max_batch asks for.
+        nb = max(1, min(self.max_batch, engine_batch_limit(self.config, latent_size)))
         key = (device.index or 0, latent_size)
         if self._engine is not None and self._engine_key[:2] == key and self._engine_key[2] == nb:
             return
