@@ -132,6 +132,23 @@ def test_sdxl_geometry_decode_256px_against_the_oracle():
     assert vae.weight_bytes > 49_000_000 * 2 * 0.98
 
 
+def test_sdxl_geometry_decode_512px_against_the_oracle():
+    """BASELINE C3's latents (64 x 64 x 4 -> 512 px) through the full SDXL-VAE geometry: 4096 attention tokens (64 MB of scores),
+    134 MB activation buffers, convolutions over 512 x 512 images."""
+    from oracle.vae_ref import TorchRefVaeDecoder
+    from transformer_latent_diffusion_amd.vae import AutoencoderKLDecoder, VaeDecoderConfig, synth_vae_state_dict
+    cfg = VaeDecoderConfig()
+    sd = synth_vae_state_dict(cfg, 0)
+    z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(6)) * 1.2
+    want = TorchRefVaeDecoder(cfg, sd).decode(z)
+    vae = AutoencoderKLDecoder(cfg, max_batch=1)
+    vae.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    got = vae.to(_dev()).decode(z.to(_dev()))[0].cpu()
+    assert got.shape == (1, 3, 512, 512)
+    e = rel_rms(got.numpy(), want.numpy())
+    assert e < VAE_IMAGE_TOL, e
+
+
 def test_three_level_decoder_64px_latents_against_the_oracle():
     """Another geometry: (64, 128, 256) with one layer per block on 64 x 64 latents -> 256 x 256 (4x): 4096 attention tokens, 256-channel
     mid block, GroupNorm statistics fused into the conv epilogues at every level that allows it and the separate kernel at the 64-channel one."""
