@@ -250,6 +250,12 @@ struct GemmParams {
     // zeros (>= 2 cv_cin: one whole pixel): taps outside the image read that zero pixel, so there is no border code in
     // the kernel.
     // cv_cin % 64 == 0; buffer size < 4 GiB; epilogues EPI_F32, EPI_BIAS_BF16, EPI_BIAS_RESID; 256- and 128-wide tiles.
+    // Block-diagonal batching of the W operand (w_batch_rows != 0; EPI_F32 / EPI_BIAS_BF16 only): the A rows are w_batch_rows-row
+    // groups stacked into one tall matrix, and group g multiplies ITS OWN W matrix at byte offset g * w_batch_stride_bytes from W
+    // (attention inside the VAE decoder: scores_b = Q_b K_b^T and O_b = P_b V_b for all samples in one launch each).
+    // w_batch_rows % 256 == 0 (a tile never straddles groups); the offset stays inside the 32-bit DMA offsets.
+    int w_batch_rows;
+    unsigned w_batch_stride_bytes;
     int conv, cv_h, cv_w, cv_up, cv_cin;
     unsigned cv_data_off;
     // conv epilogues EPI_BIAS_BF16 / EPI_BIAS_RESID: GroupNorm statistics of the OUTPUT for its consumer, fused into the epilogue

@@ -228,13 +228,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             voffA[q2] = v;
         }
         }
+        unsigned wgrp = 0;                                   // block-diagonal batching: this tile-row's own W matrix (uniform)
+        if constexpr (!F8 && !CONV && (EPI == EPI_F32 || EPI == EPI_BIAS_BF16)) {
+            if (p.w_batch_rows) wgrp = (unsigned)(tm0 / p.w_batch_rows) * p.w_batch_stride_bytes;
+        }
 #pragma unroll
         for (int q2 = 0; q2 < G::B_PIECES; ++q2) {
             const int r = (wid * G::B_PIECES + q2) * 8 + (ln >> 3);
             const int clog = (ln & 7) ^ ((r >> 1) & 7);
             int gr = tn0 + r;
             gr = gr < p.N ? gr : p.N - 1;
-            unsigned v = __umul24((unsigned)gr, (unsigned)(p.ldw * ESZ)) + (unsigned)(clog * 16);
+            unsigned v = __umul24((unsigned)gr, (unsigned)(p.ldw * ESZ)) + (unsigned)(clog * 16) + wgrp;
             asm volatile("" : "+v"(v));
             voffB[q2] = v;
         }

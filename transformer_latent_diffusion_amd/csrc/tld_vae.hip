@@ -11,7 +11,7 @@
 // page that the implicit-GEMM convolution reads for taps outside the image (GemmParams::conv, tld_gemm.hip).  The 3x3
 // convolutions (99 % of the FLOPs) are that persistent MFMA GEMM with K = 9 C_in and tap-dependent DMA row addresses; the
 // nearest-neighbour upsampling is folded into the same addressing (the 4x larger image is never written); 1x1 shortcuts,
-// the attention projections and both attention matmuls are the plain GEMM; GroupNorm statistics are a deterministic
+// the attention projections and both attention matmuls (all samples per launch, block-diagonal W) are the plain GEMM; GroupNorm statistics are a deterministic
 // two-stage fp32 / fp64 reduction and its affine + SiLU one elementwise pass.
 #include "../../include/tld_hip.h"
 #include "tld_common.h"
@@ -217,8 +217,11 @@ __global__ __launch_bounds__(256) void vae_softmax_rows_kernel(const float* __re
 }
 
 // out[c][r] = in[r][c]  (bf16; 32 x 32 tiles): V of one sample [tokens, C] (row pitch ld_in) -> V^T [C, tokens]
-__global__ void vae_transpose_kernel(const bf16* __restrict__ in, int ld_in, bf16* __restrict__ out, int ld_out, int rows, int cols) {
+//   (blockIdx.z = sample: in / out advance by in_bstride / out_bstride elements)
+__global__ void vae_transpose_kernel(const bf16* __restrict__ in, int ld_in, bf16* __restrict__ out, int ld_out, int rows, int cols,
+                                     size_t in_bstride, size_t out_bstride) {
     __shared__ bf16 tile[32][33];
+    in += blockIdx.z * in_bstride; out += blockIdx.z * out_bstride;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     for (int i = threadIdx.y; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + threadIdx.x;
@@ -287,12 +290,10 @@ struct tld_vae {
     float* io_z = nullptr;
     float2 *gn_partial = nullptr, *gn_stats = nullptr;
     int gn_max_chunks = 0;
-    // mid-block attention: the per-sample chains (scores, softmax, V^T, P V) are small launches (16 tiles each); they run
-    // round-robin on kAttnStreams side streams, each with its own scratch, forked from / joined to the caller's stream
-    static constexpr int kAttnStreams = 4;
-    float* scores[kAttnStreams] = {}; bf16* probs[kAttnStreams] = {}; bf16* vt[kAttnStreams] = {};
-    hipStream_t side[kAttnStreams] = {};
-    hipEvent_t fork_ev = nullptr, join_ev[kAttnStreams] = {};
+    // mid-block attention scratch for att_nb samples at a time: scores fp32 [att_nb][HW][HW], probabilities bf16 (same shape),
+    // V^T bf16 [att_nb][C][HW].  One batched launch per step (GemmParams::w_batch_rows): a sample alone is 16 tiles at 256 px.
+    int att_nb = 1;
+    float* scores = nullptr; bf16* probs = nullptr; bf16* vt = nullptr;
     float* out_f32 = nullptr;
 
     // GroupNorm statistics fused into the producing convolution's epilogue: true while gn_partial describes the tensor the
@@ -462,10 +463,11 @@ int conv3x3(tld_vae* v, int src, int dst, const ConvW& cw, int B, int H, int W, 
 
 // plain GEMM C[M,N] = A[M,K] W[N,K]^T with one of the three epilogues
 int gemm(tld_vae* v, const bf16* A, int lda, const bf16* Wt, int ldw, int M, int N, int K, int epi, const float* bias, bf16* out, int ldo,
-         float* c_f32, hipStream_t s) {
+         float* c_f32, hipStream_t s, int w_batch_rows = 0, size_t w_batch_stride_bytes = 0) {
     Timer t(v, VC_GEMM, s);
     GemmParams p{};
     p.A = A; p.lda = lda; p.W = Wt; p.ldw = ldw; p.M = M; p.N = N; p.K = K; p.bias = bias;
+    p.w_batch_rows = w_batch_rows; p.w_batch_stride_bytes = (unsigned)w_batch_stride_bytes;
     if (epi == EPI_BIAS_BF16) { p.out_bf16 = out; p.ldo = ldo; }
     else if (epi == EPI_BIAS_RESID) { p.resid = reinterpret_cast<resid_t*>(out); p.ldr = ldo; }
     else { p.c_f32 = c_f32; p.ldc = ldo; }
@@ -520,30 +522,23 @@ int attention(tld_vae* v, int* xi, int B, int H, int W, int C, hipStream_t s) {
     if (int rc = group_norm(v, x, t, v->attn_gn, B, HW, C, false, s)) return rc;
     if (int rc = gemm(v, v->data(t), C, v->attn_qkv.w, C, M, 3 * C, C, EPI_BIAS_BF16, v->attn_qkv.b, v->data(qkv), 3 * C, nullptr, s)) return rc;
     const float scale = 1.0f / sqrtf((float)C);
-    // with live profiling the chains stay on the caller's stream (the class timers bracket launches on one stream)
-    const int ns = v->profile ? 1 : std::min<int>(tld_vae::kAttnStreams, B);
-    if (ns > 1) {
-        HIP_TRY(hipEventRecord(v->fork_ev, s));
-        for (int i = 0; i < ns; ++i) HIP_TRY(hipStreamWaitEvent(v->side[i], v->fork_ev, 0));
-    }
-    for (int b = 0; b < B; ++b) {
-        const int si = b % ns;
-        hipStream_t st = ns > 1 ? v->side[si] : s;
-        const bf16* q = v->data(qkv) + (size_t)b * HW * 3 * C;
-        if (int rc = gemm(v, q, 3 * C, q + C, 3 * C, HW, HW, C, EPI_F32, nullptr, nullptr, HW, v->scores[si], st)) return rc;
+    // groups of `step` samples per launch: all of att_nb when a 256-row tile cannot straddle two samples, else one by one
+    const int step = HW % 256 == 0 ? v->att_nb : 1;
+    for (int b0 = 0; b0 < B; b0 += step) {
+        const int n = std::min(step, B - b0);
+        const bf16* q = v->data(qkv) + (size_t)b0 * HW * 3 * C;
+        // scores_b = Q_b K_b^T: Q of the group as one tall [n * HW, C] matrix, K_b picked per tile-row
+        if (int rc = gemm(v, q, 3 * C, q + C, 3 * C, n * HW, HW, C, EPI_F32, nullptr, nullptr, HW, v->scores, s, n > 1 ? HW : 0, (size_t)HW * 3 * C * 2)) return rc;
         {
-            Timer tm(v, VC_OTHER, st);
-            hipLaunchKernelGGL(vae_softmax_rows_kernel, dim3(HW), dim3(256), 0, st, v->scores[si], v->probs[si], HW, scale);
-            hipLaunchKernelGGL(vae_transpose_kernel, dim3((C + 31) / 32, (HW + 31) / 32), dim3(32, 8), 0, st, q + 2 * C, 3 * C, v->vt[si], HW, HW, C);
+            Timer tm(v, VC_OTHER, s);
+            hipLaunchKernelGGL(vae_softmax_rows_kernel, dim3(n * HW), dim3(256), 0, s, v->scores, v->probs, HW, scale);
+            hipLaunchKernelGGL(vae_transpose_kernel, dim3((C + 31) / 32, (HW + 31) / 32, n), dim3(32, 8), 0, s, q + 2 * C, 3 * C, v->vt, HW, HW, C,
+                               (size_t)HW * 3 * C, (size_t)C * HW);
         }
-        // o_b = P V  (tokens of sample b of buffer t, which the projections no longer need)
-        if (int rc = gemm(v, v->probs[si], HW, v->vt[si], HW, HW, C, HW, EPI_BIAS_BF16, v->zero_bias, v->data(t) + (size_t)b * HW * C, C, nullptr, st)) return rc;
+        // O_b = P_b V_b  (into the tokens of buffer t, which the projections no longer need)
+        if (int rc = gemm(v, v->probs, HW, v->vt, HW, n * HW, C, HW, EPI_BIAS_BF16, v->zero_bias, v->data(t) + (size_t)b0 * HW * C, C, nullptr, s,
+                          n > 1 ? HW : 0, (size_t)C * HW * 2)) return rc;
     }
-    if (ns > 1)
-        for (int i = 0; i < ns; ++i) {
-            HIP_TRY(hipEventRecord(v->join_ev[i], v->side[i]));
-            HIP_TRY(hipStreamWaitEvent(s, v->join_ev[i], 0));
-        }
     if (int rc = gemm(v, v->data(t), C, v->attn_out.w, C, M, C, C, EPI_BIAS_RESID, v->attn_out.b, v->data(x), C, nullptr, s)) return rc;
     v->have_partial = false;               // x changed: the statistics a convolution left behind are stale
     return check_launch("attention");
@@ -619,14 +614,11 @@ int tld_vae_create(const tld_vae_config* cfg, tld_vae** out) {
     if (int rc = dev_alloc(v, &v->gn_stats, (size_t)cfg->max_batch * v->G)) return bail(rc);
     if (cfg->mid_block_attention) {
         const size_t hw = (size_t)v->hl * v->hl;
-        for (int i = 0; i < tld_vae::kAttnStreams; ++i) {
-            if (int rc = dev_alloc(v, &v->scores[i], hw * hw)) return bail(rc);
-            if (int rc = dev_alloc(v, &v->probs[i], hw * hw)) return bail(rc);
-            if (int rc = dev_alloc(v, &v->vt[i], hw * v->C0)) return bail(rc);
-            if (hipStreamCreateWithFlags(&v->side[i], hipStreamNonBlocking) != hipSuccess) return bail(fail(TLD_ERR_HIP, "hipStreamCreate failed"));
-            if (hipEventCreateWithFlags(&v->join_ev[i], hipEventDisableTiming) != hipSuccess) return bail(fail(TLD_ERR_HIP, "hipEventCreate failed"));
-        }
-        if (hipEventCreateWithFlags(&v->fork_ev, hipEventDisableTiming) != hipSuccess) return bail(fail(TLD_ERR_HIP, "hipEventCreate failed"));
+        const size_t fit = ((size_t)256 << 20) / (hw * hw * 4);             // samples whose fp32 scores fit in 256 MB
+        v->att_nb = (int)std::max<size_t>(1, std::min<size_t>(fit, (size_t)cfg->max_batch));
+        if (int rc = dev_alloc(v, &v->scores, (size_t)v->att_nb * hw * hw)) return bail(rc);
+        if (int rc = dev_alloc(v, &v->probs, (size_t)v->att_nb * hw * hw)) return bail(rc);
+        if (int rc = dev_alloc(v, &v->vt, (size_t)v->att_nb * hw * v->C0)) return bail(rc);
     }
     if (int rc = dev_alloc(v, &v->out_f32, (size_t)cfg->max_batch * Hout * Hout * v->oc)) return bail(rc);
     *out = v;
@@ -853,11 +845,6 @@ int tld_vae_destroy(tld_vae* v) {
     clear_stages(v);
     for (int k = 0; k < VC_COUNT; ++k)
         for (auto& e : v->ev[k]) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    for (int i = 0; i < tld_vae::kAttnStreams; ++i) {
-        if (v->side[i]) { (void)hipStreamSynchronize(v->side[i]); (void)hipStreamDestroy(v->side[i]); }
-        if (v->join_ev[i]) (void)hipEventDestroy(v->join_ev[i]);
-    }
-    if (v->fork_ev) (void)hipEventDestroy(v->fork_ev);
     for (void* p : v->allocs) (void)hipFree(p);
     delete v;
     return TLD_OK;
