@@ -259,7 +259,7 @@ struct GemmParams {
     int conv, cv_h, cv_w, cv_up, cv_cin;
     unsigned cv_data_off;
     // conv epilogues EPI_BIAS_BF16 / EPI_BIAS_RESID: GroupNorm statistics of the OUTPUT for its consumer, fused into the epilogue
-    // (null: none).  partial[(sample, 256-pixel chunk)][group] = (sum, sum of squares) of the stored bf16 values, gn_cpg channels per
+    // (null: none).  partial[(sample, 256-pixel chunk)][group] = (sum, sum of squares) of the output values (bias-to-bf16 epilogue: before their rounding), gn_cpg channels per
     // group, gn_hw pixels per sample.  Requires gn_hw % 256 == 0 (a tile never straddles samples), N % 128 == 0, gn_cpg % 4 == 0.
     float2* gn_partial;
     int gn_groups, gn_cpg, gn_hw;

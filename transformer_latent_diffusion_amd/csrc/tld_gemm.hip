@@ -1038,10 +1038,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     constexpr int P = 128;
                     // CONV: GroupNorm statistics of the tile for the consumer (GemmParams::gn_partial): per lane, (sum, sum of squares)
                     // of the STORED values of its rows, one pair per 4-column quad (j, rq)
-                    float gsum[CONV ? G::TN * 4 : 1], gsq[CONV ? G::TN * 4 : 1];
+                    // (packed fp32 pairs; taken on the fp32 values BEFORE their bf16 rounding -- the rounding error is zero-mean, so a group's
+                    // mean / variance over >= 1024 values move by far less than one bf16 ulp, and the four conversions back per quad go away)
+                    f32x2 gsum[CONV ? G::TN * 4 : 1], gsq[CONV ? G::TN * 4 : 1];
                     if constexpr (CONV) {
 #pragma unroll
-                        for (int q4 = 0; q4 < G::TN * 4; ++q4) { gsum[q4] = 0.f; gsq[q4] = 0.f; }
+                        for (int q4 = 0; q4 < G::TN * 4; ++q4) { gsum[q4] = f32x2{0.f, 0.f}; gsq[q4] = f32x2{0.f, 0.f}; }
                     }
 #pragma unroll
                     for (int i = 0; i < G::TM; ++i) {
@@ -1064,16 +1066,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                         bv.z = fmaf(nm_, c4.z, bv.z); bv.w = fmaf(nm_, c4.w, bv.w);
                                     }
                                 }
+                                const f32x2 lo2 = {fmaf(rs_, acc[i][j][rq * 4 + 0], bv.x), fmaf(rs_, acc[i][j][rq * 4 + 1], bv.y)};
+                                const f32x2 hi2 = {fmaf(rs_, acc[i][j][rq * 4 + 2], bv.z), fmaf(rs_, acc[i][j][rq * 4 + 3], bv.w)};
                                 bf16x4 pk;
-                                pk[0] = (bf16)fmaf(rs_, acc[i][j][rq * 4 + 0], bv.x);
-                                pk[1] = (bf16)fmaf(rs_, acc[i][j][rq * 4 + 1], bv.y);
-                                pk[2] = (bf16)fmaf(rs_, acc[i][j][rq * 4 + 2], bv.z);
-                                pk[3] = (bf16)fmaf(rs_, acc[i][j][rq * 4 + 3], bv.w);
+                                pk[0] = (bf16)lo2[0]; pk[1] = (bf16)lo2[1]; pk[2] = (bf16)hi2[0]; pk[3] = (bf16)hi2[1];
                                 *reinterpret_cast<bf16x4*>(ws + e_l31 * P + ((((cl >> 3) ^ (e_l31 & 7)) << 4) | ((cl & 7) << 1))) = pk;
                                 if constexpr (CONV) {
-                                    const float f0 = (float)pk[0], f1 = (float)pk[1], f2 = (float)pk[2], f3 = (float)pk[3];
-                                    gsum[j * 4 + rq] += (f0 + f1) + (f2 + f3);
-                                    gsq[j * 4 + rq] = fmaf(f0, f0, fmaf(f1, f1, fmaf(f2, f2, fmaf(f3, f3, gsq[j * 4 + rq]))));
+                                    gsum[j * 4 + rq] += lo2; gsum[j * 4 + rq] += hi2;
+                                    gsq[j * 4 + rq] = __builtin_elementwise_fma(lo2, lo2, gsq[j * 4 + rq]);
+                                    gsq[j * 4 + rq] = __builtin_elementwise_fma(hi2, hi2, gsq[j * 4 + rq]);
                                 }
                             }
 #pragma unroll
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             float2* red = reinterpret_cast<float2*>(smem + ((g - 1) & 1) * G::STAGE_BYTES + 8 * G::SCRATCH);   // [WMc][BN / 4]
 #pragma unroll
                             for (int q4 = 0; q4 < G::TN * 4; ++q4) {
-                                const float a = half_sum(gsum[q4]), a2 = half_sum(gsq[q4]);
+                                const float a = half_sum(gsum[q4][0] + gsum[q4][1]), a2 = half_sum(gsq[q4][0] + gsq[q4][1]);
                                 if (e_l31 == 0) red[wm * (BN / 4) + wn * (G::WCOLS / 4) + (q4 >> 2) * 8 + (q4 & 3) * 2 + e_hi] = make_float2(a, a2);
                             }
                             gn_combine(red);
