@@ -1,0 +1,198 @@
+// gemm_w128.hip -- EXPERIMENT (not part of libtld_hip.so): bf16 GEMM C = A . W^T on gfx950 with a 128 x 128 register tile per wave.
+//
+// The shipped GEMM (csrc/tld_gemm.hip) runs 8 waves per CU on 128 x 64 (or 128 x 96) wave tiles: per 16-element k-slice a wave reads
+// 4 + 2 fragments from LDS for 8 MFMAs, and with the tile DMA written into LDS as well the LDS pipe is as loaded as the matrix pipe
+// (DESIGN.md section 9).  This kernel tests the other corner: FOUR waves per CU (one per SIMD, the 512-register wave: 256
+// accumulator registers + operands), each owning 128 x 128 of a 256 x 256 tile -- 4 + 4 fragment reads for 16 MFMAs, i.e. half the
+// LDS reads per MFMA -- with everything a second wave per SIMD used to hide done by software pipelining inside the one wave:
+// fragments of slice s + 1 are read while the 16 MFMAs of slice s execute, the last slice's MFMAs of a K-step run AFTER the
+// barrier (from registers) while the first fragments of the next stage are in flight, and the tile DMA of the next K-step is
+// spread over the four slices.  Persistent workgroups, two LDS stages, global_load_lds with the source-side XOR swizzle.
+//
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o gemm_w128 tools/ubench/gemm_w128.hip && ./gemm_w128
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <cmath>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+constexpr int PIECES = (A_BYTES + B_BYTES) / 1024 / 4;      // 1-KiB DMA pieces per wave per K-step: 16 (8 of A, 8 of W)
+
+__device__ __forceinline__ bf16x8 read_frag(const char* tile, int row, int kchunk) {
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((kchunk ^ ((row >> 1) & 7)) << 4));
+}
+
+__global__ __launch_bounds__(256) void gemm_w128_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
+                                                        int M, int N, int K, int store) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ntn = N / BN, ntiles = (M / BM) * ntn;
+    const int nk = K / BK;
+
+    unsigned voff[PIECES];                                   // pieces 0-7: A rows, 8-15: W rows of this wave
+    auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+        for (int q = 0; q < PIECES; ++q) {
+            const bool isA = q < PIECES / 2;
+            const int r = (wid * (PIECES / 2) + (isA ? q : q - PIECES / 2)) * 8 + (lane >> 3);
+            const int clog = (lane & 7) ^ ((r >> 1) & 7);
+            voff[q] = (unsigned)((isA ? m0 : n0) + r) * (unsigned)(K * 2) + (unsigned)(clog * 16);
+        }
+    };
+    auto dma = [&](int q, int kbyte, char* st) {
+        const bool isA = q < PIECES / 2;
+        const char* base = reinterpret_cast<const char*>(isA ? A : W) + kbyte;
+        char* dst = st + (isA ? 0 : A_BYTES) + (wid * (PIECES / 2) + (isA ? q : q - PIECES / 2)) * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + voff[q]), (lptr_t)dst, 16, 0, 0);
+    };
+    auto load_frags = [&](const char* st, int ks, bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+        const int kc = ks * 2 + hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = read_frag(st, wm * 128 + i * 32 + l31, kc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = read_frag(st + A_BYTES, wn * 128 + j * 32 + l31, kc);
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    set_offsets(m0, n0);
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) dma(q, 0, smem);
+    int g = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < ntiles;
+        const int m0n = has_next ? (next / ntn) * BM : 0, n0n = has_next ? (next % ntn) * BN : 0;
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        };
+        bf16x8 a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
+        for (int k = 0; k < nk; ++k, ++g) {
+            const char* st = smem + (g & 1) * STAGE;
+            char* nst = smem + ((g + 1) & 1) * STAGE;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own pieces of stage g landed
+            __builtin_amdgcn_s_barrier();                            // everybody's; everybody is done READING stage g ^ 1
+            const bool more = (k + 1 < nk) || has_next;
+            const int kb = (k + 1 < nk) ? (k + 1) * BK * 2 : 0;
+            if (k + 1 == nk && has_next) set_offsets(m0n, n0n);
+            load_frags(st, 0, a0, b0);
+            // the whole tile DMA of the NEXT K-step goes out now, one piece per deferred MFMA: it then has a full K-step (~2 k cycles of
+            // MFMAs) to land before the vmcnt(0) in front of the next barrier (pieces issued in the last slice were still in flight there)
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < PIECES; ++q) dma(q, kb, nst);
+            }
+            if (k > 0) mma(a2, b2);                                  // slice 3 of the previous step, from registers
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read (tile DMA)
+            }
+            load_frags(st, 1, a1, b1);
+            mma(a0, b0);
+            load_frags(st, 2, a0, b0);
+            mma(a1, b1);
+            load_frags(st, 3, a2, b2);
+            mma(a0, b0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // slice-3 fragments are in registers before the stage is released
+        }
+        mma(a2, b2);
+        if (store) {
+            const int row0 = m0 + wm * 128, col0 = n0 + wn * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (bf16)acc[i][j][rq * 4 + e];
+                        *reinterpret_cast<bf16x4*>(C + (size_t)(row0 + i * 32 + l31) * N + col0 + j * 32 + 8 * rq + 4 * hi) = pk;
+                    }
+        } else if (acc[0][0][0] == 12345.678f) {
+            C[0] = (bf16)1.f;                                        // (keeps the accumulators alive)
+        }
+        m0 = m0n; n0 = n0n;
+    }
+}
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int main() {
+    struct Shape { const char* name; int M, N, K; } shapes[] = {{"qkv ", 32768, 2304, 768}, {"up  ", 32768, 3072, 768}, {"down", 32768, 768, 3072},
+                                                                  {"4k  ", 4096, 4096, 4096}};
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    hipFuncAttributes fa;
+    hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gemm_w128_kernel));
+    printf("gemm_w128_kernel: %d registers per thread, %zu bytes scratch\n", fa.numRegs, (size_t)fa.localSizeBytes);
+    for (auto& s : shapes) {
+        const size_t na = (size_t)s.M * s.K, nw = (size_t)s.N * s.K, nc = (size_t)s.M * s.N;
+        std::vector<uint16_t> ha(na), hw(nw);
+        uint32_t st = 12345u;
+        auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+        for (auto& v : ha) v = f2bf(rnd());
+        for (auto& v : hw) v = f2bf(rnd() * 0.05f);
+        bf16 *dA, *dW, *dC;
+        hipMalloc(&dA, na * 2); hipMalloc(&dW, nw * 2); hipMalloc(&dC, nc * 2);
+        hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
+        hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice);
+        hipMemset(dC, 0, nc * 2);
+        const int ntiles = (s.M / BM) * (s.N / BN);
+        const int grid = ntiles < 256 ? ntiles : 256;
+        hipLaunchKernelGGL(gemm_w128_kernel, dim3(grid), dim3(256), 2 * STAGE, 0, dA, dW, dC, s.M, s.N, s.K, 1);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed: %s\n", s.name, hipGetErrorString(hipGetLastError())); return 1; }
+        std::vector<uint16_t> hc(nc);
+        hipMemcpy(hc.data(), dC, nc * 2, hipMemcpyDeviceToHost);
+        double worst = 0.0;
+        for (int t = 0; t < 2000; ++t) {
+            const size_t m = ((size_t)t * 7919 + 13) % s.M, n = ((size_t)t * 104729 + 7) % s.N;
+            double ref = 0.0;
+            for (int k = 0; k < s.K; ++k) ref += (double)bf2f(ha[m * s.K + k]) * (double)bf2f(hw[n * s.K + k]);
+            const double got = bf2f(hc[m * s.N + n]);
+            worst = fmax(worst, fabs(got - ref) / (fabs(ref) + 0.05));
+        }
+        for (int mode = 1; mode >= 0; --mode) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_w128_kernel, dim3(grid), dim3(256), 2 * STAGE, 0, dA, dW, dC, s.M, s.N, s.K, mode);
+            hipEventRecord(e0, 0);
+            const int iters = 20;
+            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(gemm_w128_kernel, dim3(grid), dim3(256), 2 * STAGE, 0, dA, dW, dC, s.M, s.N, s.K, mode);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            const double us = ms * 1e3 / iters, tf = 2.0 * s.M * s.N * s.K / (us * 1e-6) / 1e12;
+            printf("%s M=%d N=%d K=%d %s: %8.1f us  %7.1f TFLOP/s (%.1f%% of 2500)   max rel err (2000 samples) %.2e\n", s.name, s.M, s.N, s.K,
+                   mode ? "with stores" : "no stores  ", us, tf, tf / 25.0, worst);
+        }
+        hipFree(dA); hipFree(dW); hipFree(dC);
+    }
+    return 0;
+}
