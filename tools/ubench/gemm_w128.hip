@@ -33,7 +33,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* tile, int row, int kchun
 }
 
 __global__ __launch_bounds__(256) void gemm_w128_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
-                                                        int M, int N, int K, int store) {
+                                                        int M, int N, int K, int store, int dbg) {      // dbg (attribution): 1 = no fragment reads after the first, 2 = no tile DMA in the loop
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void gemm_w128_kernel(const bf16* __restrict__
     const int ntn = N / BN, ntiles = (M / BM) * ntn;
     const int nk = K / BK;
 
+    bool g_started = false;
     unsigned voff[PIECES];                                   // pieces 0-7: A rows, 8-15: W rows of this wave
     auto set_offsets = [&](int m0, int n0) {
 #pragma unroll
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void gemm_w128_kernel(const bf16* __restrict__
         __builtin_amdgcn_global_load_lds((gptr_t)(base + voff[q]), (lptr_t)dst, 16, 0, 0);
     };
     auto load_frags = [&](const char* st, int ks, bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+        if ((dbg & 1) && g_started) return;
         const int kc = ks * 2 + hi;
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = read_frag(st, wm * 128 + i * 32 + l31, kc);
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_w128_kernel(const bf16* __restrict__
             load_frags(st, 0, a0, b0);
             // the whole tile DMA of the NEXT K-step goes out now, one piece per deferred MFMA: it then has a full K-step (~2 k cycles of
             // MFMAs) to land before the vmcnt(0) in front of the next barrier (pieces issued in the last slice were still in flight there)
-            if (more) {
+            if (more && !(dbg & 2)) {
 #pragma unroll
                 for (int q = 0; q < PIECES; ++q) dma(q, kb, nst);
             }
@@ -118,6 +120,7 @@ __global__ __launch_bounds__(256) void gemm_w128_kernel(const bf16* __restrict__
             mma(a1, b1);
             load_frags(st, 3, a2, b2);
             mma(a0, b0);
+            g_started = true;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // slice-3 fragments are in registers before the stage is released
         }
         mma(a2, b2);
@@ -141,6 +144,114 @@ __global__ __launch_bounds__(256) void gemm_w128_kernel(const bf16* __restrict__
     }
 }
 
+
+// ---- variant 2: BK = 32, FOUR LDS stages of 32 KiB (prefetch distance 3 K-steps = 96 KiB in flight per CU instead of 64) -------------
+// Little's law on variant 1: one 64-KiB stage in flight per CU x ~2 us of load latency = 32 GB/s per CU = 8 TB/s over the chip, which is the
+// operand rate a ~1.05 PFLOP/s GEMM on 256 x 256 tiles needs -- the K loop is bound by how much tile data is in flight, not by LDS or MFMA.
+// Rows are 64 bytes here (4 chunks of 16 B); the swizzle is chunk ^ ((row >> 2) & 3), conflict-free per 16-lane read group.
+constexpr int BK2 = 32, NST2 = 4;
+constexpr int A2_BYTES = BM * BK2 * 2, B2_BYTES = BN * BK2 * 2, STAGE2 = A2_BYTES + B2_BYTES;      // 16 + 16 KiB
+constexpr int PIECES2 = STAGE2 / 1024 / 4;                                                        // 8 pieces per wave per K-step (4 A, 4 W), 16 rows each
+
+__global__ __launch_bounds__(256) void gemm_w128_s4_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
+                                                           int M, int N, int K, int store, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ntn = N / BN, ntiles = (M / BM) * ntn;
+    const int nk = K / BK2;
+    unsigned voff[PIECES2];
+    auto set_offsets = [&](int m0, int n0) {
+#pragma unroll
+        for (int q = 0; q < PIECES2; ++q) {
+            const bool isA = q < PIECES2 / 2;
+            const int r = (wid * (PIECES2 / 2) + (isA ? q : q - PIECES2 / 2)) * 16 + (lane >> 2);
+            const int clog = (lane & 3) ^ ((r >> 2) & 3);
+            voff[q] = (unsigned)((isA ? m0 : n0) + r) * (unsigned)(K * 2) + (unsigned)(clog * 16);
+        }
+    };
+    auto dma = [&](int q, int kbyte, char* st) {
+        const bool isA = q < PIECES2 / 2;
+        const char* base = reinterpret_cast<const char*>(isA ? A : W) + kbyte;
+        char* dst = st + (isA ? 0 : A2_BYTES) + (wid * (PIECES2 / 2) + (isA ? q : q - PIECES2 / 2)) * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + voff[q]), (lptr_t)dst, 16, 0, 0);
+    };
+    auto rd = [&](const char* t, int row, int kc) { return *reinterpret_cast<const bf16x8*>(t + row * 64 + ((kc ^ ((row >> 2) & 3)) << 4)); };
+    auto load_frags = [&](const char* st, int ks, bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+        const int kc = ks * 2 + hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = rd(st, wm * 128 + i * 32 + l31, kc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = rd(st + A2_BYTES, wn * 128 + j * 32 + l31, kc);
+    };
+    // linear K-step stream over all of this workgroup's tiles: step s of the stream = (tile s / nk, k = s % nk)
+    int my_tiles = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) ++my_tiles;
+    const int total = my_tiles * nk;
+    int issued = 0;
+    auto issue_step = [&](int s2) {                      // DMA of stream step s2 into stage s2 % NST2
+        const int tl = blockIdx.x + (s2 / nk) * gridDim.x, k = s2 % nk;
+        if (k == 0) set_offsets((tl / ntn) * BM, (tl % ntn) * BN);
+        char* st = smem + (s2 % NST2) * STAGE2;
+#pragma unroll
+        for (int q = 0; q < PIECES2; ++q) dma(q, k * BK2 * 2, st);
+    };
+    for (; issued < NST2 - 1 && issued < total; ++issued) issue_step(issued);
+    int s2 = 0;
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tl = blockIdx.x + it * gridDim.x;
+        const int m0 = (tl / ntn) * BM, n0 = (tl % ntn) * BN;
+        f32x16 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        };
+        bf16x8 a0[4], b0[4], a1[4], b1[4];
+        for (int k = 0; k < nk; ++k, ++s2) {
+            const char* st = smem + (s2 % NST2) * STAGE2;
+            // stage s2 must have landed: at most the NST2 - 2 younger steps' pieces may still be in flight (vmcnt counts this wave's own)
+            const int younger = issued - s2 - 1;             // steps issued after s2
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                    // everybody's pieces of s2; everybody finished reading stage (s2 - 1) % NST2
+            if (issued < total && !(dbg & 2)) { issue_step(issued); ++issued; }      // refills the stage read in the previous step
+            else if (issued < total) ++issued;
+            load_frags(st, 0, a0, b0);
+            load_frags(st, 1, a1, b1);
+            mma(a0, b0);
+            mma(a1, b1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (store) {
+            const int row0 = m0 + wm * 128, col0 = n0 + wn * 128;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (bf16)acc[i][j][rq * 4 + e];
+                        *reinterpret_cast<bf16x4*>(C + (size_t)(row0 + i * 32 + l31) * N + col0 + j * 32 + 8 * rq + 4 * hi) = pk;
+                    }
+        } else if (acc[0][0][0] == 12345.678f) {
+            C[0] = (bf16)1.f;
+        }
+    }
+}
+
 static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
 static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
@@ -148,6 +259,7 @@ int main() {
     struct Shape { const char* name; int M, N, K; } shapes[] = {{"qkv ", 32768, 2304, 768}, {"up  ", 32768, 3072, 768}, {"down", 32768, 768, 3072},
                                                                   {"4k  ", 4096, 4096, 4096}};
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w128_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_w128_s4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, NST2 * STAGE2);
     hipFuncAttributes fa;
     hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(gemm_w128_kernel));
     printf("gemm_w128_kernel: %d registers per thread, %zu bytes scratch\n", fa.numRegs, (size_t)fa.localSizeBytes);
@@ -165,7 +277,14 @@ int main() {
         hipMemset(dC, 0, nc * 2);
         const int ntiles = (s.M / BM) * (s.N / BN);
         const int grid = ntiles < 256 ? ntiles : 256;
-        hipLaunchKernelGGL(gemm_w128_kernel, dim3(grid), dim3(256), 2 * STAGE, 0, dA, dW, dC, s.M, s.N, s.K, 1);
+        for (int variant = 0; variant < 2; ++variant) {
+        auto launch = [&](int store, int dbg) {
+            if (variant == 0) hipLaunchKernelGGL(gemm_w128_kernel, dim3(grid), dim3(256), 2 * STAGE, 0, dA, dW, dC, s.M, s.N, s.K, store, dbg);
+            else hipLaunchKernelGGL(gemm_w128_s4_kernel, dim3(grid), dim3(256), NST2 * STAGE2, 0, dA, dW, dC, s.M, s.N, s.K, store, dbg);
+        };
+        hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice);
+        hipMemset(dC, 0, nc * 2);
+        launch(1, 0);
         if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed: %s\n", s.name, hipGetErrorString(hipGetLastError())); return 1; }
         std::vector<uint16_t> hc(nc);
         hipMemcpy(hc.data(), dC, nc * 2, hipMemcpyDeviceToHost);
@@ -177,20 +296,24 @@ int main() {
             const double got = bf2f(hc[m * s.N + n]);
             worst = fmax(worst, fabs(got - ref) / (fabs(ref) + 0.05));
         }
-        for (int mode = 1; mode >= 0; --mode) {
+        struct { const char* label; int store, dbg, zeros; } modes[] = {{"no stores          ", 0, 0, 0}, {"no stores, zeros   ", 0, 0, 1}, {"no stores, no DMA  ", 0, 2, 0}};
+        for (auto& md : modes) {
+            if (variant == 0 && md.dbg == 0 && md.zeros == 0) {}
+            if (md.zeros) { hipMemset(dA, 0, na * 2); hipMemset(dW, 0, nw * 2); }
+            else { hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice); }
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
-            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_w128_kernel, dim3(grid), dim3(256), 2 * STAGE, 0, dA, dW, dC, s.M, s.N, s.K, mode);
+            for (int i = 0; i < 3; ++i) launch(md.store, md.dbg);
             hipEventRecord(e0, 0);
             const int iters = 20;
-            for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(gemm_w128_kernel, dim3(grid), dim3(256), 2 * STAGE, 0, dA, dW, dC, s.M, s.N, s.K, mode);
+            for (int i = 0; i < iters; ++i) launch(md.store, md.dbg);
             hipEventRecord(e1, 0);
             hipEventSynchronize(e1);
             float ms = 0.f;
             hipEventElapsedTime(&ms, e0, e1);
             const double us = ms * 1e3 / iters, tf = 2.0 * s.M * s.N * s.K / (us * 1e-6) / 1e12;
-            printf("%s M=%d N=%d K=%d %s: %8.1f us  %7.1f TFLOP/s (%.1f%% of 2500)   max rel err (2000 samples) %.2e\n", s.name, s.M, s.N, s.K,
-                   mode ? "with stores" : "no stores  ", us, tf, tf / 25.0, worst);
+            printf("%s %s %s: %8.1f us  %7.1f TFLOP/s (%.1f%% of 2500)   max rel err %.2e\n", s.name, variant ? "BK32 x 4 stages" : "BK64 x 2 stages", md.label, us, tf, tf / 25.0, worst);
+        }
         }
         hipFree(dA); hipFree(dW); hipFree(dC);
     }
