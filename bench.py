@@ -259,11 +259,18 @@ def main():
         model.set_profile((dom_cls,))
         model.reserve_profile(dom_cls, warm_prof[dom_cls][1] * args.steps)    # no hipEventCreate inside the timed region
     fence()
+    # per-step boundaries as events on the launch stream (no synchronisation inside the timed region): the median step time
+    #  is reported beside the contract's wall-clock mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        marks[i].record()
         out = one_step()
+    marks[args.steps].record()
     fence()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     assert torch.isfinite(out).all()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -318,6 +325,8 @@ def main():
                        "images_per_gpu": B, "global_batch": total, "n_iter": N_ITER, "class_guidance": CFG,
                        "parallelism": f"dp{world} (sample-sharded, one all-gather)" if world > 1 else "single GPU"},
             "ms_per_denoise_step": ms_per_step / N_ITER,
+            "ms_per_step_median": median_ms, "ms_per_step_min": step_ms[0], "ms_per_step_max": step_ms[-1],
+            "value_at_median_step": total / (median_ms * 1e-3),
         }
         # whole-step MFMA fractions.  "algorithmic" = the REFERENCE's op count per image / time:
         # the fraction of the 774 img/s ceiling.  "executed" = the flops the engine's kernels actually perform (no

@@ -3,9 +3,13 @@ openai/CLIP-keyed state_dict.
 
 TEST INFRASTRUCTURE ONLY, like everything under ``oracle/``.
 
-**Parity: unpinned.**  The algorithm lives in a third-party dependency -- openai/CLIP ("ViT-L/14", tld/configs.py:46-48; the
-reference installs it from git, unpinned) -- absent from /root/reference and from this image, and the reference's tests stub the
-text encoder, so there is no golden vector to anchor on.  Restated from clip/model.py:
+**Parity: pinned against an independent published implementation.**  The algorithm lives in a third-party dependency -- openai/CLIP
+("ViT-L/14", tld/configs.py:46-48; the reference installs it from git, unpinned) -- absent from /root/reference and from this image,
+and the reference's tests stub the text encoder.  HuggingFace ``transformers.CLIPTextModelWithProjection`` (5.15.0, importable in the
+build container) is the same tower; ``oracle/gen_golden_clip.py`` loads the synthetic weights into it and records tokens ->
+``text_embeds`` / ``last_hidden_state`` in ``tests/golden/g13_clip_text.npz`` (ViT-L/14 geometry and a tiny one).  This restatement
+agrees with it to 4e-7 rel-rms (tests/test_clip_host.py holds it to 1e-5); the HIP tower is compared with the same fixture
+(tests/test_gpu_clip.py).  Restated from clip/model.py:
 
 * ``encode_text``: ``x = token_embedding(text) + positional_embedding``; ``x = transformer(x)`` (sequence-first there; the math is
   per sample); ``x = ln_final(x)``; ``x[arange(B), text.argmax(-1)] @ text_projection``
@@ -33,7 +37,7 @@ class TorchRefClipText:
                                            for k, v in state_dict.items()}
 
     @torch.no_grad()
-    def encode_text(self, text: torch.Tensor) -> torch.Tensor:
+    def encode_text(self, text: torch.Tensor, return_hidden: bool = False):
         w, d, h = self.w, self.width, self.heads
         b, n = text.shape
         x = w["token_embedding.weight"][text.long()] + w["positional_embedding"][:n]
@@ -51,6 +55,7 @@ class TorchRefClipText:
             y = y * torch.sigmoid(1.702 * y)
             x = x + F.linear(y, w[p + "mlp.c_proj.weight"], w[p + "mlp.c_proj.bias"])
         x = F.layer_norm(x, (d,), w["ln_final.weight"], w["ln_final.bias"], 1e-5)
-        return x[torch.arange(b), text.argmax(dim=-1)] @ w["text_projection"]
+        pooled = x[torch.arange(b), text.argmax(dim=-1)] @ w["text_projection"]
+        return (pooled, x) if return_hidden else pooled
 
     __call__ = encode_text

@@ -24,6 +24,7 @@ Fixtures:
   g9_ln_stress.npz        d=768, L=2 model whose residual rows carry a large common offset (|row mean| / row std ~ 4, 28 and 85 at
                           the first norm1): stresses LayerNorm statistics (the engine's folded LayerNorm-1 / -3 paths)
   g11_100m_512px_traj.npz C3 sampler: 100M model at image_size=64, 35-step CFG=6 DPM-2M end latent, B=1
+  g14_100m_1024px_traj.npz C4 sampler: image_size=128 (4096 tokens), 35-step CFG=6 DPM-2M end latent, B=1 (fp32)
 
 Usage: python oracle/gen_golden.py            (all fixtures)
        python oracle/gen_golden.py g9 g11     (only the named ones; names are matched by prefix)
@@ -292,6 +293,23 @@ def c3_traj_fixture():
          traj_class_guidance=np.float64(6.0), traj_latent=lat, traj_x0_first=rec["x0"][0])
 
 
+def c4_traj_fixture():
+    """g14: BASELINE C4 shape (image_size 128 = 4096 tokens), 35-step CFG-6 DPM-2M trajectory of one image in fp32 -- what the
+    bf16 AND the MX-fp8 engines are held against (the reference has no fp8 path: its fp32 run is the only anchor there is)."""
+    cfg = config_100m(128)
+    m, ck = build_ref(cfg, 8)                   # same weights as g8
+    gen = DiffusionGenerator(m, FakeVAE(), torch.device("cpu"), torch.float32)
+    g = torch.Generator().manual_seed(141)
+    seeds = torch.randn(1, 4, 128, 128, generator=g)
+    labels = torch.randn(1, 768, generator=g) * 0.5
+    cap = {}
+    lat, rec = run_generate(gen, cap, labels=labels, n_iter=35, num_imgs=1, class_guidance=6.0,
+                            seeds=seeds.clone(), img_size=128, sharp_f=0.0, bright_f=0.0, exponent=1)
+    save("g14_100m_1024px_traj.npz", cfg=cfg_arr(cfg), weight_seed=np.int64(8), weight_checksum=np.array(ck),
+         traj_seeds=seeds.numpy(), traj_labels=labels.numpy(), traj_n_iter=np.int64(35),
+         traj_class_guidance=np.float64(6.0), traj_latent=lat, traj_x0_first=rec["x0"][0])
+
+
 def _c4():
     c4 = config_100m(); c4.n_layers = 1
     return c4
@@ -308,6 +326,7 @@ FIXTURES = {
     "g8": lambda: forward_fixture("g8_100m_1024px.npz", config_100m(128), 8, 1, 88),
     "g9": ln_stress_fixture,
     "g11": c3_traj_fixture,
+    "g14": c4_traj_fixture,
 }
 
 if __name__ == "__main__":

@@ -1,6 +1,9 @@
 """CPU tests of the CLIP text front edge: key / shape plan against the published parameter count, the
-oracle restatement against independently constructed torch.nn modules (nn.MultiheadAttention with the causal mask), and the
-no-CPU-path rule."""
+oracle restatement against the fixture captured from transformers.CLIPTextModelWithProjection (g13, oracle/gen_golden_clip.py) and
+against independently constructed torch.nn modules (nn.MultiheadAttention with the causal mask), and the no-CPU-path rule."""
+import os
+import zlib
+
 from collections import OrderedDict
 
 import numpy as np
@@ -108,3 +111,31 @@ def test_load_state_dict_and_no_cpu_path():
         enc.encode_text(_tokens(TINY, 1, 0))
     with pytest.raises(ValueError):
         enc.encode_text(torch.zeros(1, 5, dtype=torch.long))
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g13_clip_text.npz")
+
+
+def load_g13(tag):
+    """(cfg, state_dict, tokens, text_embeds, last_hidden_state[:2]) of fixture geometry ``tag``; weights regenerated from the seed
+    and checked against the stored checksum."""
+    g = np.load(GOLDEN)
+    cfg = ClipTextConfig(*[int(v) for v in g[f"{tag}:cfg"]])
+    sd = synth_clip_state_dict(cfg, int(g[f"{tag}:seed"]))
+    crc = 0
+    for k in sd:
+        crc = zlib.crc32(np.ascontiguousarray(sd[k]).tobytes(), crc)
+    assert crc == int(g[f"{tag}:weights_crc32"]), "synthetic CLIP weights differ from the ones the fixture was generated with"
+    return cfg, sd, torch.from_numpy(g[f"{tag}:tokens"]).long(), g[f"{tag}:text_embeds"], g[f"{tag}:last_hidden_state"]
+
+
+@pytest.mark.parametrize("tag", ["tiny", "l14"])
+def test_restatement_pinned_against_transformers_clip(tag):
+    """oracle/clip_ref.py vs HuggingFace's CLIPTextModelWithProjection on the same weights and tokens: <= 1e-5 rel-rms, max-abs 1e-4
+    (measured 4e-7); both the pooled projected embedding (= encode_text) and the ln_final hidden states."""
+    cfg, sd, text, want, want_hid = load_g13(tag)
+    got, hid = TorchRefClipText(cfg, sd).encode_text(text, return_hidden=True)
+    rel = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    assert got.shape == want.shape
+    assert rel(got.numpy(), want) < 1e-5 and float(np.abs(got.numpy() - want).max()) < 1e-4
+    assert rel(hid.numpy()[:2], want_hid) < 1e-5

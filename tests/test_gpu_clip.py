@@ -1,5 +1,6 @@
-"""GPU: the CLIP text tower through the C ABI (tld_clip_*), against the fp32 restatement of
-openai/CLIP's encode_text (oracle/clip_ref.py; parity unpinned against the clip package itself, see its header).
+"""GPU: the CLIP text tower through the C ABI (tld_clip_*), against the fixture captured from
+transformers.CLIPTextModelWithProjection (g13, oracle/gen_golden_clip.py) and against the fp32 restatement of openai/CLIP's
+encode_text (oracle/clip_ref.py, itself pinned to that fixture).
 Tolerance: bf16 projection operands with fp32 residual stream / LayerNorm / softmax -- CLIP_TOL rel-rms on the [B, 768] output, the
 denoiser's own forward tolerance (the reference runs this tower in fp16, tld/configs.py:48; the MFMA GEMM here is bf16)."""
 import ctypes as C
@@ -10,7 +11,7 @@ import pytest
 import torch
 
 from conftest import rel_rms
-from test_clip_host import TINY, _tokens
+from test_clip_host import TINY, _tokens, load_g13
 from test_gpu_parity import _dev
 
 pytestmark = pytest.mark.gpu
@@ -53,6 +54,20 @@ def test_vit_l14_text_tower_against_the_oracle():
     print(f"clip ViT-L/14 text tower rel-rms {e:.2e}")
     assert got.shape == (4, 768) and e < CLIP_TOL, e
     assert enc.weight_bytes > 85_000_000 * 2                      # bf16 block weights + fp32 embeddings
+
+
+@pytest.mark.parametrize("tag", ["tiny", "l14"])
+def test_text_tower_against_transformers_fixture(tag):
+    """tld_clip_encode_text vs HuggingFace's CLIPTextModelWithProjection outputs on the same synthetic weights and tokens (g13):
+    CLIP_TOL rel-rms on the pooled projected embedding -- no restatement of ours in the loop."""
+    from transformer_latent_diffusion_amd.clip_text import ClipTextEncoder
+    cfg, sd, text, want, _ = load_g13(tag)
+    enc = ClipTextEncoder(cfg, max_batch=8)
+    enc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    got = enc.to(_dev()).encode_text(text.to(_dev())).cpu().numpy()
+    e = rel_rms(got, want)
+    print(f"clip text tower ({tag}) vs transformers fixture: rel-rms {e:.2e}")
+    assert got.shape == want.shape and e < CLIP_TOL, e
 
 
 def test_pipeline_shell_keeps_labels_on_the_device():

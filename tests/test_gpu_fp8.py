@@ -18,6 +18,7 @@ from test_gpu_parity import _dev, _t
 
 pytestmark = pytest.mark.gpu
 
+FP8_TRAJ_TOL = 1.5e-1     # 35-step CFG-6 end latent rel-rms vs the fp32 reference trajectory (g14; stated by this build -- the reference has no fp8 mode)
 FP8_FWD_TOL = 6e-2        # forward rel-rms vs the fp32 reference with all QKV / MLP GEMMs in MX-fp8 (measured 2.5e-2 .. 4.6e-2: DESIGN.md 4.4)
 
 
@@ -103,6 +104,23 @@ def test_fp8_c4_sampler_shape_runs():
     assert torch.equal(two, gen.generate_latents(labels, num_imgs=2, seeds=seeds, **kw))
 
 
+def test_fp8_c4_trajectory_vs_fp32_reference():
+    """C4 end to end: 35 steps + CFG 6 at 1024 px (4096 tokens) with MX-fp8 QKV / MLP GEMMs against the reference's fp32 trajectory
+    (g14).  The reference has no fp8 path, so this tolerance is the build's own statement (unpinned by the reference): first CFG
+    prediction <= FP8_FWD_TOL (6e-2), 35-step end latent <= FP8_TRAJ_TOL (1.5e-1); the bf16 engine meets 2e-2 / 6e-2 on the same
+    fixture (test_gpu_configs.py::test_c4_sampler_1024px_bf16)."""
+    from transformer_latent_diffusion_amd import DiffusionGenerator
+    g = load_golden("g14_100m_1024px_traj.npz")
+    cfg, m = _fp8_engine(g)
+    gen = DiffusionGenerator(m, None, _dev(), torch.float32)
+    kw = dict(n_iter=int(g["traj_n_iter"]), class_guidance=float(g["traj_class_guidance"]), img_size=128, sharp_f=0.0, bright_f=0.0)
+    one, tx0, _ = gen.generate_latents(torch.from_numpy(g["traj_labels"]), num_imgs=1, seeds=torch.from_numpy(g["traj_seeds"]), trace=True, **kw)
+    e0 = rel_rms(tx0[0].cpu().numpy(), g["traj_x0_first"])
+    r = rel_rms(one.cpu().numpy(), g["traj_latent"])
+    print(f"C4 fp8: first CFG prediction rel-rms {e0:.2e}, 35-step end latent {r:.2e}")
+    assert e0 <= FP8_FWD_TOL and r <= FP8_TRAJ_TOL, (e0, r)
+
+
 @pytest.mark.parametrize("name", ["g5_100m.npz", "g7_100m_512px.npz"])
 def test_fp8_quantising_producers_equal_separate_passes(name):
     """The LayerNorm / cross-attention / tiled depthwise kernels write the MX-fp8 operands themselves; with
@@ -115,8 +133,9 @@ def test_fp8_quantising_producers_equal_separate_passes(name):
         os.environ["TLD_FP8_FUSED"] = fused
         try:
             cfg, m = _fp8_engine(g)
-            m.reserve(8)                                 # the switch is read when the engine is created
+            m.reserve(8)                                 # the switch is read when the engine is created ...
+            assert g["x"].shape[0] <= 8                  # ... and a larger batch would rebuild it
+            outs.append(m(_t(g["x"]), _t(g["sigma"]), _t(g["label"])).cpu().numpy())    # (forward inside the scope, so a rebuild could not flip the mode either)
         finally:
             os.environ.pop("TLD_FP8_FUSED", None) if old is None else os.environ.__setitem__("TLD_FP8_FUSED", old)
-        outs.append(m(_t(g["x"]), _t(g["sigma"]), _t(g["label"])).cpu().numpy())
     assert np.array_equal(outs[0], outs[1])

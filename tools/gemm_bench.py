@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from transformer_latent_diffusion_amd import _lib
 
-SHAPES = [("qkv", 32768, 2304, 768, 1), ("up", 32768, 3072, 768, 2), ("updw", 32768, 3072, 768, 4), ("updw2", 32768, 3072, 768, 6), ("down", 32768, 768, 3072, 3)]
+SHAPES = [("4k", 4096, 4096, 4096, 2), ("qkv", 32768, 2304, 768, 1), ("up", 32768, 3072, 768, 2), ("updw", 32768, 3072, 768, 4), ("updw2", 32768, 3072, 768, 6), ("down", 32768, 768, 3072, 3)]
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 only = sys.argv[2] if len(sys.argv) > 2 else None
 L = _lib.lib()

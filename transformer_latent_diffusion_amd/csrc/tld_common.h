@@ -265,6 +265,8 @@ struct GemmParams {
     int gn_groups, gn_cpg, gn_hw;
     unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0
+    int desync_cycles;            // experiment knob (TLD_GEMM_DESYNC=<shader cycles>): every second workgroup of an XCD starts that much later, so the
+                                  // epilogue (store / VALU) phases of half the CUs fall into the K loops of the other half
     int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop
     int dbg_epi;                  // experiment knob, builds with -DTLD_DBG_EPI only (TLD_EPI_DBG bit mask, see tld_gemm.hip)
 };

@@ -857,7 +857,8 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     HIP_TRY(hipMalloc(&bias, (size_t)N * 4)); HIP_TRY(hipMalloc(&res, (size_t)M * N * 4));
     const float zs = getenv("TLD_GEMM_ZERO") ? 0.0f : 1.0f;     // DVFS experiment: all-zero operands
     launch_fill_bf16(A, (int64_t)M * K, 1u, 1.0f * zs, nullptr);
-    launch_fill_bf16(W, (int64_t)N * K, 2u, 0.05f * zs, nullptr);
+    const float wsc = getenv("TLD_GEMM_WSCALE") ? (float)atof(getenv("TLD_GEMM_WSCALE")) : 0.05f;     // 1.0: both operands uniform in [-1, 1) (the GEMM template's benchmark data)
+    launch_fill_bf16(W, (int64_t)N * K, 2u, wsc * zs, nullptr);
     HIP_TRY(hipMemset(bias, 0, (size_t)N * 4)); HIP_TRY(hipMemset(res, 0, (size_t)M * N * 4));
     GemmParams g{};
     g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;

@@ -27,6 +27,10 @@
 #define TLD_KLOOP_NS 1        // k-slices per barrier interval of the staggered K loop (1 or 2); the 384-wide tile always uses 1
 #endif
 
+#ifndef TLD_KLOOP_RING
+#define TLD_KLOOP_RING 1      // counted-vmcnt half-tile ring K loop for 256 x 256 tiles (see kloop_ring); 0 = never instantiate it.  TLD_GEMM_RING=0 in the environment keeps the two-stage loop at run time (same-box A/B)
+#endif
+
 #ifndef TLD_GLDS_AUX
 #define TLD_GLDS_AUX 0      // cache-policy bits of the tile DMA (experiment knob: 2 = nt; measured slower)
 #endif
@@ -113,9 +117,10 @@ struct G256P : G256<BN> {
 // (scale layout [K/128][rows][4], see GemmParams).  Used for BASELINE config C4 (QKV / MLP GEMMs in fp8).
 // CONV = true: implicit 3x3 convolution over a channels-last image (GemmParams::conv): only the A-side DMA addressing
 // differs -- the per-lane row offsets are recomputed whenever the K loop moves to the next of the 9 taps.
-template <int BN, int EPI, bool F8 = false, bool CONV = false>
+template <int BN, int EPI, bool F8 = false, bool CONV = false, bool RING = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks) {
     using G = G256P<BN>;
+    static_assert(!RING || (BN == 256 && !F8 && !CONV && TLD_KLOOP_STAGGER), "the half-tile ring exists for plain bf16 256 x 256 tiles");
     using frag_t = std::conditional_t<F8, i32x8, bf16x8>;
     constexpr int ESZ = F8 ? 1 : 2;                                     // operand bytes per element
     constexpr int SC_OFF = G::LDS_BYTES;                                // F8: [stage][A scales 1 KiB | W scales 1 KiB] behind the stages
@@ -169,6 +174,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         }
     };
     if (my_tiles == 0) return;
+    if (p.desync_cycles > 0 && (lidx & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.desync_cycles) __builtin_amdgcn_s_sleep(16);
+    }
 
     const int nk = CONV ? 9 * (p.cv_cin >> 6) : p.K * ESZ / (G::BK * 2);   // 128-byte K-steps
     // DMA addressing: a uniform 64-bit base (operand + K offset, SGPRs) plus one 32-bit byte offset per piece and
@@ -301,9 +310,56 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         }
     };
 
+    // ---- half-tile ring (RING): see kloop_ring below.  A half-tile is 128 operand rows x 64 K (16 KiB, same row image and swizzle as
+    // a stage's), brought in by two 1-KiB pieces per wave.  Half-tile A_h holds the rows {wm * 128 + h * 64 + [0, 64)} of the tile and
+    // B_h the W rows {wn * 64 + h * 32 + [0, 32)}: quadrant (qa, qb) of every wave's 128 x 64 output reads exactly A_qa and B_qb.
+    constexpr int HT = 16384;
+    unsigned rvA[RING ? 4 : 1], rvB[RING ? 4 : 1];            // [half * 2 + piece]: per-lane source byte offsets
+    auto ring_offsets = [&](int tm0, int tn0) {
+        if constexpr (RING) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            unsigned wgrp = 0;
+            if constexpr (EPI == EPI_F32 || EPI == EPI_BIAS_BF16) {
+                if (p.w_batch_rows) wgrp = (unsigned)(tm0 / p.w_batch_rows) * p.w_batch_stride_bytes;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int r = (wid * 2 + q2) * 8 + (ln >> 3);                      // row of the half-tile image
+                    const unsigned c16 = (unsigned)(((ln & 7) ^ ((r >> 1) & 7)) * 16);
+                    int ga = tm0 + (r >> 6) * 128 + h * 64 + (r & 63);
+                    ga = ga < p.M ? ga : p.M - 1;
+                    unsigned va = __umul24((unsigned)ga, (unsigned)(p.lda * 2)) + c16;
+                    int gb = tn0 + (r >> 5) * 64 + h * 32 + (r & 31);
+                    gb = gb < p.N ? gb : p.N - 1;
+                    unsigned vb = __umul24((unsigned)gb, (unsigned)(p.ldw * 2)) + c16 + wgrp;
+                    asm volatile("" : "+v"(va), "+v"(vb));
+                    rvA[h * 2 + q2] = va;
+                    rvB[h * 2 + q2] = vb;
+                }
+        }
+    };
+    // stream element i of K-tile tk: 0 = B0, 1 = A0, 2 = B1, 3 = A1 (the order in which a K-tile's half-tiles are first read)
+    auto ring_stage = [&](auto ic, int tk, int slot) {
+        if constexpr (RING) {
+            constexpr int i = decltype(ic)::value;
+            constexpr bool isA = (i & 1) != 0;
+            constexpr int half = i >> 1;
+            const char* base = reinterpret_cast<const char*>(isA ? (const void*)p.A : (const void*)p.W) + (size_t)tk * (G::BK * 2);
+            asm volatile("" : "+s"(base));         // one SGPR pair + a 32-bit lane offset per piece (no 64-bit vector address arithmetic)
+            char* dst = smem + slot * HT + wid * 2048;
+            unsigned o0 = isA ? rvA[half * 2] : rvB[half * 2], o1 = isA ? rvA[half * 2 + 1] : rvB[half * 2 + 1];
+            asm volatile("" : "+v"(o0), "+v"(o1));   // (keeps the zero-extension next to the load: saddr + 32-bit voffset form)
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + o0), (lptr_t)dst, 16, 0, TLD_GLDS_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + o1), (lptr_t)(dst + 1024), 16, 0, TLD_GLDS_AUX);
+        }
+    };
+
     int m0, n0;
     tile_coords(0, m0, n0);
-    issue(m0, n0, 0);
+    if constexpr (!RING) issue(m0, n0, 0);
     int g = 0;                                        // global K-step counter (ring position)
     int ctap = 0, ccb = 0;                            // CONV: (tap, 64-channel block) of the K-step whose DMA was issued last
     const int kpt = CONV ? (p.cv_cin >> 6) : 1;       // K-steps per tap
@@ -329,6 +385,49 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 
         frag_t a0[G::TM], b0[G::TN], a1[G::TM], b1[G::TN];
         int sca[G::TM], scb[G::TN];                 // F8: this K-step's scale dwords of the lane's rows (already shifted by 8 hi)
+        // per-tile side tables of the folded LayerNorms (row partial sums / (mean, rstd) pairs, column constants): DMA into LDS behind
+        // the operand ring; issued in K-step 1 of the two-stage loop and at the tile start of the ring loop (every wave is then past
+        // the previous tile's epilogue, which read them)
+        auto aux_dma = [&]() {
+            if constexpr (LN) {
+                static_assert(kLnSlots == 8, "one partial-sum row is 64 B");
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int piece = wid * 2 + q2;
+                    int row = m0 + piece * 16 + (lane >> 2);
+                    row = row < p.M ? row : p.M - 1;
+                    const char* src = reinterpret_cast<const char*>(p.ln_stats) + (size_t)row * 64 + (lane & 3) * 16;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_RAW + piece * 1024), 16, 0, 0);
+                }
+                if (wid < 2) {                                    // wave 0: c1, wave 1: b1 of the tile's columns (4 per lane)
+                    int col = n0 + lane * 4;
+                    col = col < p.N ? col : 0;
+                    const float* src = (wid == 0 ? p.ln_c1 : p.ln_b1) + col;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_CB + wid * 1024), 16, 0, 0);
+                }
+            }
+            if constexpr (EPI == EPI_BIAS_BF16) {      // folded LayerNorm-3 of the plain up-projection (grids other than 16 x 16)
+                if (p.row_stats && wid < 2) {
+                    int r0s = m0 + wid * 128 + lane * 2;                     // 2 rows (16 B) per lane, clamped at the matrix end
+                    r0s = r0s + 1 < p.M ? r0s : (p.M >= 2 ? p.M - 2 : 0);
+                    const char* src = reinterpret_cast<const char*>(p.row_stats + r0s);
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::PLAINRS_OFF + wid * 1024), 16, 0, 0);
+                }
+            }
+            if constexpr (EPI == EPI_UP_DWCONV || EPI == EPI_UP_DWCONV2) {
+                constexpr int RS_OFF = EPI == EPI_UP_DWCONV ? G::ROWSTAT_OFF : G::ROWSTAT2_OFF;
+                if (p.row_stats && wid < 2) {
+                    const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + RS_OFF + wid * 1024), 16, 0, 0);
+                }
+                if constexpr (EPI == EPI_UP_DWCONV2) {      // waves 2 / 3: c1 / bias of the tile's columns
+                    if (wid == 3 || (wid == 2 && p.row_stats)) {
+                        const float* src = (wid == 2 ? p.ln_c1 : p.bias) + n0 + lane * 4;
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::CB2_OFF + (wid - 2) * 1024), 16, 0, 0);
+                    }
+                }
+            }
+        };
         auto kloop = [&](auto swp) {
             constexpr bool SW = decltype(swp)::value;
             auto mma = [&](const frag_t (&a)[G::TM], const frag_t (&b)[G::TN], auto slice) {
@@ -373,46 +472,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             __builtin_amdgcn_s_barrier();          // ... everybody's; also: the previous epilogue's scratch reads are done
             if (grp) __builtin_amdgcn_s_barrier(); // stagger in
             for (int k = 0; k < nk; ++k, ++g) {
-                if constexpr (LN) {
-                    if (k == 1) {
-                        static_assert(kLnSlots == 8, "one partial-sum row is 64 B");
-#pragma unroll
-                        for (int q2 = 0; q2 < 2; ++q2) {
-                            const int piece = wid * 2 + q2;
-                            int row = m0 + piece * 16 + (lane >> 2);
-                            row = row < p.M ? row : p.M - 1;
-                            const char* src = reinterpret_cast<const char*>(p.ln_stats) + (size_t)row * 64 + (lane & 3) * 16;
-                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_RAW + piece * 1024), 16, 0, 0);
-                        }
-                        if (wid < 2) {
-                            int col = n0 + lane * 4;
-                            col = col < p.N ? col : 0;
-                            const float* src = (wid == 0 ? p.ln_c1 : p.ln_b1) + col;
-                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_CB + wid * 1024), 16, 0, 0);
-                        }
-                    }
-                }
-                if constexpr (EPI == EPI_BIAS_BF16) {      // folded LayerNorm-3 of the plain up-projection (grids other than 16 x 16)
-                    if (k == 1 && p.row_stats && wid < 2) {
-                        int r0s = m0 + wid * 128 + lane * 2;                     // 2 rows (16 B) per lane, clamped at the matrix end
-                        r0s = r0s + 1 < p.M ? r0s : (p.M >= 2 ? p.M - 2 : 0);
-                        const char* src = reinterpret_cast<const char*>(p.row_stats + r0s);
-                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::PLAINRS_OFF + wid * 1024), 16, 0, 0);
-                    }
-                }
-                if constexpr (EPI == EPI_UP_DWCONV || EPI == EPI_UP_DWCONV2) {
-                    constexpr int RS_OFF = EPI == EPI_UP_DWCONV ? G::ROWSTAT_OFF : G::ROWSTAT2_OFF;
-                    if (k == 1 && p.row_stats && wid < 2) {
-                        const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
-                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + RS_OFF + wid * 1024), 16, 0, 0);
-                    }
-                    if constexpr (EPI == EPI_UP_DWCONV2) {      // waves 2 / 3: c1 / bias of the tile's columns
-                        if (k == 1 && (wid == 3 || (wid == 2 && p.row_stats))) {
-                            const float* src = (wid == 2 ? p.ln_c1 : p.bias) + n0 + lane * 4;
-                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::CB2_OFF + (wid - 2) * 1024), 16, 0, 0);
-                        }
-                    }
-                }
+                if (k == 1) aux_dma();
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
                 const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV && EPI != EPI_UP_DWCONV2);
@@ -502,50 +562,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 stamp(k, 1);
                 __builtin_amdgcn_s_barrier();      // everybody's; stage (g+1)&1 (operands or epilogue scratch) is idle
                 stamp(k, 2);
-                if constexpr (LN) {
-                    // folded LayerNorm-1: the tile's 256 rows of partial sums (64 B each) travel by DMA into LDS behind
-                    // the stages while the K loop runs; two 1-KiB pieces (16 rows each) per wave
-                    if (k == 1) {
-                        static_assert(kLnSlots == 8, "one partial-sum row is 64 B");
-#pragma unroll
-                        for (int q2 = 0; q2 < 2; ++q2) {
-                            const int piece = wid * 2 + q2;
-                            int row = m0 + piece * 16 + (lane >> 2);
-                            row = row < p.M ? row : p.M - 1;
-                            const char* src = reinterpret_cast<const char*>(p.ln_stats) + (size_t)row * 64 + (lane & 3) * 16;
-                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_RAW + piece * 1024), 16, 0, 0);
-                        }
-                        if (wid < 2) {                                    // wave 0: c1, wave 1: b1 of the tile's columns (4 per lane)
-                            int col = n0 + lane * 4;
-                            col = col < p.N ? col : 0;
-                            const float* src = (wid == 0 ? p.ln_c1 : p.ln_b1) + col;
-                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::LN_CB + wid * 1024), 16, 0, 0);
-                        }
-                    }
-                }
-                if constexpr (EPI == EPI_BIAS_BF16) {      // folded LayerNorm-3 of the plain up-projection (grids other than 16 x 16)
-                    if (k == 1 && p.row_stats && wid < 2) {
-                        int r0s = m0 + wid * 128 + lane * 2;                     // 2 rows (16 B) per lane, clamped at the matrix end
-                        r0s = r0s + 1 < p.M ? r0s : (p.M >= 2 ? p.M - 2 : 0);
-                        const char* src = reinterpret_cast<const char*>(p.row_stats + r0s);
-                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::PLAINRS_OFF + wid * 1024), 16, 0, 0);
-                    }
-                }
-                if constexpr (EPI == EPI_UP_DWCONV || EPI == EPI_UP_DWCONV2) {
-                    // folded LayerNorm-3: the tile's 256 (mean, rstd) pairs travel by DMA into LDS behind the image while
-                    // the K loop runs (K-step 1: every wave is past the previous tile's epilogue, which read them)
-                    constexpr int RS_OFF = EPI == EPI_UP_DWCONV ? G::ROWSTAT_OFF : G::ROWSTAT2_OFF;
-                    if (k == 1 && p.row_stats && wid < 2) {
-                        const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
-                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + RS_OFF + wid * 1024), 16, 0, 0);
-                    }
-                    if constexpr (EPI == EPI_UP_DWCONV2) {      // waves 2 / 3: c1 / bias of the tile's columns
-                        if (k == 1 && (wid == 3 || (wid == 2 && p.row_stats))) {
-                            const float* src = (wid == 2 ? p.ln_c1 : p.bias) + n0 + lane * 4;
-                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::CB2_OFF + (wid - 2) * 1024), 16, 0, 0);
-                        }
-                    }
-                }
+                if (k == 1) aux_dma();
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
                 const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV && EPI != EPI_UP_DWCONV2);
@@ -590,7 +607,140 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             if constexpr (BN != 384) mma(a1, b1, std::integral_constant<int, 0>{});  // k-slice 3 of the tile's last step
 #endif
         };
-        if constexpr (swapped) kloop(std::true_type{}); else kloop(std::false_type{});
+        // ---- Half-tile ring K loop (RING; the counted-vmcnt 8-phase structure of the gfx950 GEMM template, on 32x32x16 MFMAs).
+        //   LDS: 8 half-tile slots = 2 K-tiles x {B0, A0, B1, A1}.  An iteration is 8 phases = 2 K-tiles; phase p:
+        //     R half: ds_read the quadrant's operand subtile | stage ONE half-tile of the stream (2 pieces per wave)
+        //     s_barrier, lgkmcnt(0), 8 MFMAs (one C quadrant x K = 64) at raised priority, s_barrier.
+        //   Quadrants per K-tile: (0,0) (0,1) (1,1) (1,0); reads: B0 + A0 | B1 | A1 | none (B0 stays in registers).  Waves 4-7 run one
+        //   barrier behind waves 0-3, so the two waves of a SIMD alternate between the R and the M half.
+        //   The half-tile stream runs 6 phases ahead of its first read (phase P stages element P + 6).  s_waitcnt vmcnt(6) in phases 4
+        //   and 8 only: three half-tiles stay in flight, never 0 inside a tile's main loop; a half-tile is first read in the phase AFTER
+        //   the wait that retired it.  WAR: a slot is restaged >= 2 phases after its last read, except B0 (1 phase), whose reads are
+        //   issued first and retired by lgkmcnt(8) before the reading phase's first barrier.
+        //   Tile boundary: the next tile's K-tile 0 is staged in phases 2-5 of the last iteration (slots 0-3) and lands under the
+        //   epilogue, whose scratch is slots 4-7; its K-tile 1 elements B0 A0 B1 are staged right after the epilogue.  The fused
+        //   depthwise epilogues own the whole ring (the image), so their tiles start cold.
+        auto kloop_ring = [&](auto swp) {
+            if constexpr (RING) {
+            constexpr bool SW = decltype(swp)::value;
+            constexpr bool NOXT = EPI == EPI_UP_DWCONV || EPI == EPI_UP_DWCONV2;
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+            const int grp = wid >> 2;
+            const int nj = nk >> 1;
+            const bool xt = has_next && !NOXT;
+            if (it == 0 || NOXT) {
+                aux_dma();
+                ring_offsets(m0, n0);
+                ring_stage(I0{}, 0, 0); ring_stage(I1{}, 0, 1); ring_stage(I2{}, 0, 2); ring_stage(I3{}, 0, 3);
+                ring_stage(I0{}, 1, 4); ring_stage(I1{}, 1, 5); ring_stage(I2{}, 1, 6);
+                wait_vmcnt<6>();                   // K-tile 0 (and the side tables) landed: own pieces ...
+                __builtin_amdgcn_s_barrier();      // ... everybody's
+            } else {
+                __builtin_amdgcn_s_barrier();      // every wave is done with its epilogue scratch (slots 4-7)
+                aux_dma();
+                ring_stage(I0{}, 1, 4); ring_stage(I1{}, 1, 5); ring_stage(I2{}, 1, 6);
+            }
+            frag_t fa[2][4], fb0[4], fb1[4];
+            // fragment read addresses: one register per (operand, k-slice) -- byte offset of (row, chunk (2 ks + hi) ^ swizzle) inside a
+            // half-tile image; the slot and the A row-block are immediates, and the registers flip between the two K-tiles' slot groups
+            // (bit 16) as the loop goes: no per-read address arithmetic
+            unsigned ra[4], rb[4];
+            {
+                int l31v = l31, hiv = hi;
+                asm volatile("" : "+v"(l31v), "+v"(hiv));
+                const int sw = (l31v >> 1) & 7;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    ra[ks] = (unsigned)((wm * 64 + l31v) * 128 + (((ks * 2 + hiv) ^ sw) << 4));
+                    rb[ks] = (unsigned)((wn * 32 + l31v) * 128 + (((ks * 2 + hiv) ^ sw) << 4));
+                    asm volatile("" : "+v"(ra[ks]), "+v"(rb[ks]));
+                }
+            }
+            auto rd = [&](unsigned a, int imm) { return *reinterpret_cast<const frag_t*>(smem + a + imm); };
+            if (grp) __builtin_amdgcn_s_barrier(); // stagger in
+            auto iter = [&](int j, auto lastc) {
+                constexpr bool last = decltype(lastc)::value;
+                auto phase = [&](auto pc) {
+                    constexpr int ph = decltype(pc)::value;          // 1 .. 8
+                    constexpr int q = (ph - 1) & 3;
+                    // ---- R half   (slots of this K-tile: B0 A0 B1 A1 at 0, HT, 2 HT, 3 HT from the current slot group)
+                    if constexpr (q == 0) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) fb0[ks] = rd(rb[ks], 0);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) fa[ii][ks] = rd(ra[ks], HT + ii * 4096);
+                    } else if constexpr (q == 1) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) fb1[ks] = rd(rb[ks], 2 * HT);
+                    } else if constexpr (q == 2) {
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                            for (int ks = 0; ks < 4; ++ks) fa[ii][ks] = rd(ra[ks], 3 * HT + ii * 4096);
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(rb[ks]));     // B reads of this K-tile are issued: other slot group
+                    } else {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(ra[ks]));
+                    }
+                    {
+                        constexpr int i = (ph + 6) & 3, slot = (ph + 6) & 7, dk = (ph + 6) >> 2;
+                        using IC = std::integral_constant<int, i>;
+                        if constexpr (ph == 1 || !last) ring_stage(IC{}, 2 * j + dk, slot);
+                        else if constexpr (ph <= 5) {            // last iteration: the next tile's K-tile 0
+                            if (xt) {
+                                if constexpr (ph == 2) ring_offsets(m0n, n0n);
+                                ring_stage(IC{}, 0, slot);
+                            }
+                        }
+                    }
+                    if constexpr (ph == 4) {
+                        if (last && !xt) wait_vmcnt<0>(); else wait_vmcnt<6>();
+                    }
+                    if constexpr (ph == 8 && !last) wait_vmcnt<6>();
+                    if constexpr (q == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // B0 reads retired: its slot is restaged next phase
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- M half: one C quadrant x K = 64
+                    constexpr int qa = (q >= 2) ? 1 : 0, qb = (q == 1 || q == 2) ? 1 : 0;
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {
+                            const frag_t& bf = qb ? fb1[ks] : fb0[ks];
+                            if constexpr (SW) acc[qa * 2 + ii][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, fa[ii][ks], acc[qa * 2 + ii][qb], 0, 0, 0);
+                            else acc[qa * 2 + ii][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ii][ks], bf, acc[qa * 2 + ii][qb], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                phase(std::integral_constant<int, 1>{}); phase(std::integral_constant<int, 2>{});
+                phase(std::integral_constant<int, 3>{}); phase(std::integral_constant<int, 4>{});
+                phase(std::integral_constant<int, 5>{}); phase(std::integral_constant<int, 6>{});
+                phase(std::integral_constant<int, 7>{}); phase(std::integral_constant<int, 8>{});
+            };
+            for (int j = 0; j + 1 < nj; ++j) iter(j, std::false_type{});
+            iter(nj - 1, std::true_type{});
+            if (xt) wait_vmcnt<0>();                   // the next tile's K-tile 0 (own pieces), before this tile's stores are issued
+            if (!grp) __builtin_amdgcn_s_barrier();    // stagger out: both groups are past their last MFMA
+            g += nk;
+            }
+        };
+        if constexpr (RING) {
+            if constexpr (swapped) kloop_ring(std::true_type{}); else kloop_ring(std::false_type{});
+        } else {
+            if constexpr (swapped) kloop(std::true_type{}); else kloop(std::false_type{});
+        }
 
         const int row0 = m0 + wm * G::WROWS;
         const int col0 = n0 + wn * G::WCOLS;
@@ -628,7 +778,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 }
         } else {
             __builtin_amdgcn_s_barrier();          // all waves finished reading the last stage: reuse it as scratch
-            char* ws = smem + ((g - 1) & 1) * G::STAGE_BYTES + wid * G::SCRATCH;
+            char* ws = RING ? smem + 4 * HT + wid * G::SCRATCH : smem + ((g - 1) & 1) * G::STAGE_BYTES + wid * G::SCRATCH;   // (ring: slots 4-7 are free by now)
             if constexpr (EPI == EPI_UP_DWCONV) {
                 // The tile's 256 rows are the 16x16 tokens of ONE sample, so the depthwise 3x3 conv of the MLP is
                 // tile-local: hidden = bf16(acc + bias) goes to LDS as [256 tokens][256 channels] (128 KB: both
@@ -770,7 +920,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 }
                 // the ring restarts for the next tile: its first K-step could not be prefetched (LDS was the image)
                 __builtin_amdgcn_s_barrier();
-                if (has_next) issue(m0n, n0n, g);
+                if constexpr (!RING) { if (has_next) issue(m0n, n0n, g); }   // (ring: the next tile starts cold in kloop_ring)
             } else if constexpr (EPI == EPI_UP_DWCONV2) {
                 // Second form of the fused depthwise 3x3 + GELU epilogue.  The K loop runs in the NATURAL MFMA order, so a
                 // lane owns a channel and four consecutive tokens (= four consecutive image columns of one image row)
@@ -904,7 +1054,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 }
                 // the ring restarts for the next tile: its first K-step could not be prefetched (LDS was the image)
                 __builtin_amdgcn_s_barrier();
-                if (has_next) issue(m0n, n0n, g);
+                if constexpr (!RING) { if (has_next) issue(m0n, n0n, g); }   // (ring: the next tile starts cold in kloop_ring)
             } else if constexpr (EPI == EPI_BIAS_RESID) {
                 constexpr int P = 32 * 4 + 16;      // one 32x32 fp32 tile, padded pitch
                 float gsum[CONV ? G::TN : 1], gsq[CONV ? G::TN : 1];     // CONV: GroupNorm partials of this lane's column quad (lane & 7) per 32-column block
@@ -1157,10 +1307,26 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     // 55 MB algorithmic) while A is fetched by two XCDs instead of one: 235 -> 228 us.  Measured and rejected:
     // four groups for the up-projection (neutral), two / four groups for the down-projection (A is the 201 MB
     // operand there: neutral / 175 -> 195 us).  Large launches only: every XCD cell needs workgroups of its own.
+    // half-tile ring K loop (256 x 256 tiles, bf16, no conv): an iteration is two K-tiles, so K must be a multiple of 128
+    static const bool ring_env = !(getenv("TLD_GEMM_RING") && atoi(getenv("TLD_GEMM_RING")) == 0);        // A/B knob
+    const bool use_ring = ring_env && p.K >= 128 && p.K % 128 == 0;
+    (void)use_ring;
     GemmParams pg = p;
+    static const int desync_env = getenv("TLD_GEMM_DESYNC") ? atoi(getenv("TLD_GEMM_DESYNC")) : 0;
+    if (desync_env) pg.desync_cycles = desync_env;
     if ((epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
         pg.xcd_ngroups = 2;
 #define TLD_L256P_(E, F8) TLD_L256P__(E, F8, false)
+#define TLD_L256P_LAUNCH(E, F8, CV, RG)                                                               \
+    do {                                                                                              \
+        static bool once = false;                                                                     \
+        if (!once) {                                                                                  \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E, F8, CV, RG>),    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
+            once = true;                                                                              \
+        }                                                                                             \
+        hipLaunchKernelGGL((gemm256p_kernel<BN, E, F8, CV, RG>), grid, block, lds, s, pg, nblocks);   \
+    } while (0)
 #define TLD_L256P__(E, F8, CV)                                                                        \
     do {                                                                                              \
         constexpr int lds = (F8) ? G::LDS_BYTES + 4096                                                \
@@ -1168,13 +1334,12 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
                             : ((E) == EPI_UP_DWCONV2 ? G::UPDW2_LDS                                   \
                             : ((E) == EPI_QKV_LN ? G::QKVLN_LDS                                        \
                             : ((E) == EPI_BIAS_BF16 ? G::PLAINLN_LDS : G::LDS_BYTES))));              \
-        static bool once = false;                                                                     \
-        if (!once) {                                                                                  \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E, F8, CV>),        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
-            once = true;                                                                              \
+        constexpr bool ring_ok = TLD_KLOOP_RING && BN == 256 && !(F8) && !(CV);                       \
+        if constexpr (ring_ok) {                                                                      \
+            if (use_ring) TLD_L256P_LAUNCH(E, F8, CV, true); else TLD_L256P_LAUNCH(E, F8, CV, false); \
+        } else {                                                                                      \
+            TLD_L256P_LAUNCH(E, F8, CV, false);                                                       \
         }                                                                                             \
-        hipLaunchKernelGGL((gemm256p_kernel<BN, E, F8, CV>), grid, block, lds, s, pg, nblocks);       \
     } while (0)
 #define TLD_L256P(E) TLD_L256P_(E, false)
     if (p.conv) {           // implicit 3x3 convolution (VAE decoder): 256- or 128-wide tiles, three epilogues
@@ -1213,6 +1378,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
         }
     }
 #undef TLD_L256P__
+#undef TLD_L256P_LAUNCH
 #undef TLD_L256P_
 #undef TLD_L256P
 }
