@@ -208,7 +208,33 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const bf16* __restrict__ A,
         if (!grp) __builtin_amdgcn_s_barrier();          // stagger out
         stamp(5);
 
-        if (store) {
+        if (store >= 5) {
+            // store modes 5 / 6 (plain / nontemporal): no LDS round trip.  Swapped accumulators: lane (l31, hi) holds, per 32 x 32 tile and
+            // register quad rq, the 4 columns 8 rq + 4 hi + [0, 4) of row l31 -- 8 bytes.  One v_permlane32_swap per packed dword pair
+            // exchanges quads between the two lane halves, after which lane (l31, hi) owns the 8 consecutive columns 16 k + 8 hi + [0, 8)
+            // (k = 0, 1): 16-byte stores, 32 bytes per row per instruction.
+            const int row0 = m0 + wr * 128, col0 = n0 + wc * 64;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        unsigned x[2], y[2];
+#pragma unroll
+                        for (int w2 = 0; w2 < 2; ++w2) {
+                            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+                            bf16x2 a, b;
+                            a[0] = (bf16)acc[i][j2][(2 * k2) * 4 + 2 * w2]; a[1] = (bf16)acc[i][j2][(2 * k2) * 4 + 2 * w2 + 1];
+                            b[0] = (bf16)acc[i][j2][(2 * k2 + 1) * 4 + 2 * w2]; b[1] = (bf16)acc[i][j2][(2 * k2 + 1) * 4 + 2 * w2 + 1];
+                            const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+                            x[w2] = r[0]; y[w2] = r[1];
+                        }
+                        const u32x4 v = {x[0], x[1], y[0], y[1]};
+                        u32x4* dst = reinterpret_cast<u32x4*>(C + (size_t)(row0 + i * 32 + l31) * N + col0 + j2 * 32 + 16 * k2 + 8 * hi);
+                        if (store == 6) __builtin_nontemporal_store(v, dst); else *dst = v;
+                    }
+        } else if (store) {
             // swapped accumulators: lane = token row, registers = 4 consecutive columns per quad.  One 32-row x 64-col bf16 slab at a
             // time through the wave's scratch (128-B pitch, chunks XOR (row & 7)), then whole 128-B rows with 16-B stores.
             char* ws = smem + SCR_OFF + wid * 4096;
@@ -253,6 +279,7 @@ static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(
 
 int main(int argc, char** argv) {
     const int screen_runs = argc > 1 ? atoi(argv[1]) : 6;
+    const int check_store = argc > 2 ? atoi(argv[2]) : 1;
     struct Shape { const char* name; int M, N, K; } shapes[] = {{"256 ", 256, 256, 256}, {"512 ", 512, 512, 512}, {"4k  ", 4096, 4096, 4096},
                                                                   {"qkv ", 32768, 2304, 768}, {"up  ", 32768, 3072, 768}, {"down", 32768, 768, 3072},
                                                                   {"8k  ", 8192, 8192, 8192}};
@@ -286,7 +313,7 @@ int main(int argc, char** argv) {
         int mismatching_runs = 0;
         for (int run = 0; run < screen_runs; ++run) {
             hipMemset(dC, 0xff, nc * 2);
-            launch(1, 0);
+            launch(check_store, 0);
             if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed: %s\n", s.name, hipGetErrorString(hipGetLastError())); return 1; }
             hipMemcpy(hc.data(), dC, nc * 2, hipMemcpyDeviceToHost);
             if (run == 0) {
@@ -306,7 +333,8 @@ int main(int argc, char** argv) {
         if (s.M < 1024) { hipFree(dA); hipFree(dW); hipFree(dC); continue; }
         struct { const char* label; int store, dbg, zeros; } modes[] = {{"full (with stores)", 1, 0, 0}, {"no stores         ", 0, 0, 0}, {"no stores, zeros  ", 0, 0, 1},
                                                                         {"no stores, no DMA ", 0, 2, 0}, {"no stores, no frag", 0, 1, 0}, {"DMA + barriers only", 0, 5, 0},
-                                                                        {"LDS transpose only", 2, 0, 0}, {"global stores only", 3, 0, 0}, {"nontemporal stores", 4, 0, 0}};
+                                                                        {"LDS transpose only", 2, 0, 0}, {"global stores only", 3, 0, 0}, {"nontemporal stores", 4, 0, 0},
+                                                                        {"permlane, 16-B stores", 5, 0, 0}, {"permlane, 16-B NT   ", 6, 0, 0}};
         for (auto& md : modes) {
             if (md.zeros) { hipMemset(dA, 0, na * 2); hipMemset(dW, 0, nw * 2); }
             else { hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice); }

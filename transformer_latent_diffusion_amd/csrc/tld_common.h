@@ -102,8 +102,24 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
 // GELU of 2y given y (the fused depthwise epilogue halves the conv weights and bias on the host -- exact -- so the conv
 // delivers y = x / 2):  GELU(x) = y (1 + erf(sqrt2 y)), with sqrt2^i folded into the A&S coefficients.  Two packed
 // multiplies per pair fewer than gelu_erf_fast2(x).
+#ifndef TLD_GELU_POLY4
+#define TLD_GELU_POLY4 1      // 1: erfc by Abramowitz-Stegun 7.1.27 (four coefficients, ^-4, |erf error| <= 5e-4) in the bf16-rounded MLP epilogues;
+#endif                        // 0: 7.1.28 (six coefficients, ^-16, 3e-7).  See DESIGN.md 4.1 for the parity it was judged by.
 __device__ __forceinline__ f32x2 gelu_erf_fast2_half(f32x2 y) {
     const f32x2 ay = __builtin_elementwise_abs(y);
+#if TLD_GELU_POLY4
+    // erfc(sqrt2 |y|) = (1 + b1 |y| + b2 |y|^2 + b3 |y|^3 + b4 |y|^4)^-4,  b_i = a_i sqrt2^i of A&S 7.1.27: four packed FMAs and two
+    // squarings instead of six and four.  The GELU's absolute error is <= 2.5e-4 |x| (x = 2 y), i.e. below the bf16 rounding of the
+    // stored activation (2^-9 relative) wherever |GELU| is not itself tiny, and O(1e-3) absolute on the negative tail where the
+    // exact value is ~ -1e-3 .. -1e-2: invisible in the forward / trajectory rel-rms (profiles/r03_parity_report.md).
+    f32x2 p = __builtin_elementwise_fma(f32x2{0.312432f, 0.312432f}, ay, f32x2{0.00274923f, 0.00274923f});
+    p = __builtin_elementwise_fma(p, ay, f32x2{0.460778f, 0.460778f});
+    p = __builtin_elementwise_fma(p, ay, f32x2{0.393707156f, 0.393707156f});
+    p = __builtin_elementwise_fma(p, ay, f32x2{1.0f, 1.0f});
+    f32x2 r4 = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+    r4 *= r4; r4 *= r4;
+    return __builtin_elementwise_fma(-ay, r4, y + ay);
+#else
     f32x2 p = __builtin_elementwise_fma(f32x2{0.0003445104f, 0.0003445104f}, ay, f32x2{0.001564500341f, 0.001564500341f});
     p = __builtin_elementwise_fma(p, ay, f32x2{0.0006080572f, 0.0006080572f});
     p = __builtin_elementwise_fma(p, ay, f32x2{0.02622101059f, 0.02622101059f});
@@ -114,6 +130,7 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2_half(f32x2 y) {
     r *= r; r *= r; r *= r; r *= r;                                                      // erfc(sqrt2 |y|)
     // y (1 + erf(sqrt2 y)) = (y + |y|) - |y| erfc(sqrt2 |y|)  for either sign of y: no copysign / select needed
     return __builtin_elementwise_fma(-ay, r, y + ay);
+#endif
 }
 // (A transcendental-free degree-9 polynomial erf was measured ~4 % SLOWER end to end: its 10-deep dependent FMA
 // chain is latency-bound at the 2 waves/SIMD of the fused GEMM epilogue.)
@@ -265,8 +282,6 @@ struct GemmParams {
     int gn_groups, gn_cpg, gn_hw;
     unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0
-    int desync_cycles;            // experiment knob (TLD_GEMM_DESYNC=<shader cycles>): every second workgroup of an XCD starts that much later, so the
-                                  // epilogue (store / VALU) phases of half the CUs fall into the K loops of the other half
     int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop
     int dbg_epi;                  // experiment knob, builds with -DTLD_DBG_EPI only (TLD_EPI_DBG bit mask, see tld_gemm.hip)
 };

@@ -174,10 +174,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         }
     };
     if (my_tiles == 0) return;
-    if (p.desync_cycles > 0 && (lidx & 1)) {
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.desync_cycles) __builtin_amdgcn_s_sleep(16);
-    }
 
     const int nk = CONV ? 9 * (p.cv_cin >> 6) : p.K * ESZ / (G::BK * 2);   // 128-byte K-steps
     // DMA addressing: a uniform 64-bit base (operand + K offset, SGPRs) plus one 32-bit byte offset per piece and
@@ -1309,11 +1305,10 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     // operand there: neutral / 175 -> 195 us).  Large launches only: every XCD cell needs workgroups of its own.
     // half-tile ring K loop (256 x 256 tiles, bf16, no conv): an iteration is two K-tiles, so K must be a multiple of 128
     static const bool ring_env = !(getenv("TLD_GEMM_RING") && atoi(getenv("TLD_GEMM_RING")) == 0);        // A/B knob
-    const bool use_ring = ring_env && p.K >= 128 && p.K % 128 == 0;
+    static const int ring_mask = getenv("TLD_GEMM_RING_MASK") ? atoi(getenv("TLD_GEMM_RING_MASK")) : 0x7f;   // A/B knob: bit e = epilogue e may use the ring
+    const bool use_ring = ring_env && ((ring_mask >> epilogue) & 1) && p.K >= 128 && p.K % 128 == 0;
     (void)use_ring;
     GemmParams pg = p;
-    static const int desync_env = getenv("TLD_GEMM_DESYNC") ? atoi(getenv("TLD_GEMM_DESYNC")) : 0;
-    if (desync_env) pg.desync_cycles = desync_env;
     if ((epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
         pg.xcd_ngroups = 2;
 #define TLD_L256P_(E, F8) TLD_L256P__(E, F8, false)
