@@ -230,6 +230,39 @@ TLD_API int tld_clip_destroy(tld_clip* c);
 
 TLD_API const char* tld_last_error(void);
 
+/* ---- Training step: tld/train.py:162-173 for one batch on one device -------------------------------------------
+ * The model's parameters, their gradients, Adam's two moment vectors and the EMA copy are FLAT fp32 device vectors owned by the
+ * caller, in the order of Denoiser.named_parameters() (tld/denoiser.py:85-114); tld_train_param_layout enumerates (key, offset,
+ * numel).  The gradient all-reduce of the reference's accelerate/DDP wrapper (tld/train.py:114,168) is the caller's
+ * torch.distributed all_reduce on the flat gradient vector between tld_train_forward_backward and tld_train_adam_ema.
+ * cfg.max_batch = largest batch (NOT doubled); 256-token latents (image_size / patch_size == 16) only. */
+typedef struct tld_train tld_train;
+TLD_API int tld_train_create(const tld_config* cfg, tld_train** out);
+TLD_API int64_t tld_train_param_count(const tld_train* e);
+TLD_API int32_t tld_train_tensor_count(const tld_train* e);
+TLD_API int tld_train_param_layout(const tld_train* e, int32_t index, char* key_out, int32_t key_cap, int64_t* offset, int64_t* numel);
+/* registered buffer "fourier_feats.0.angular_speeds" (tld/transformer_blocks.py:11-15): host fp32 [noise_embed_dims / 2] */
+TLD_API int tld_train_set_angular_speeds(tld_train* e, const float* host, int32_t n);
+/* params / grads: device fp32 [tld_train_param_count] */
+TLD_API int tld_train_bind(tld_train* e, float* params, float* grads);
+/* bf16 GEMM operands (and their transposes) of the current parameters; called automatically after an optimizer step */
+TLD_API int tld_train_refresh_weights(tld_train* e, void* hip_stream);
+/* model.train(); pred = model(x_noisy, noise_level.view(-1, 1), label); loss = nn.MSELoss()(pred, target); loss.backward()
+ * -- tld/train.py:160,166-168.  x_noisy / target [batch, C, S, S], noise_level [batch], label [batch, text_emb]: device fp32.
+ * Writes every gradient into the bound grads vector (overwritten, like zero_grad + backward), the scalar loss to loss_out (device
+ * fp32[1]) and the prediction to pred_out (device fp32 [batch, C, S, S]). */
+TLD_API int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* noise_level, const float* label, const float* target,
+                                       int32_t batch, float* loss_out, float* pred_out, void* hip_stream);
+/* optimizer.step() of torch.optim.Adam(lr) + update_ema(ema_model, model, alpha) -- tld/train.py:87,169,55-58,172.  step counts from 1;
+ * ema may be NULL; grad_scale multiplies the gradient first (1 / world_size after a SUM all-reduce). */
+TLD_API int tld_train_adam_ema(tld_train* e, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel,
+                               float lr, float beta1, float beta2, float eps, int32_t step, float ema_alpha, float grad_scale, void* hip_stream);
+/* Test hook: self-attention backward alone (256 tokens, head_dim 64): qk [M, 2d] bf16 (q | k), vt [B, H, 64, 256] bf16, o [M, d] bf16
+ * (forward output), g [M, d] fp32 (dL/dO) -> dqkv [M, 3d] bf16 (dq | dk | dv).  Device pointers. */
+TLD_API int tld_debug_attention_bwd(const void* qk, const void* vt, const void* o, const float* g, void* dqkv, int32_t batch, int32_t heads,
+                                    void* hip_stream);
+TLD_API int tld_train_destroy(tld_train* e);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,10 @@ class TorchRefDenoiser:
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, noise_level: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+        return self.forward_graph(x, noise_level, label)
+
+    def forward_graph(self, x: torch.Tensor, noise_level: torch.Tensor, label: torch.Tensor) -> torch.Tensor:
+        """The same graph without ``no_grad``: the training-step oracle (``train_step`` below) differentiates it with autograd."""
         w, d, pz, g = self.w, self.d, self.patch, self.grid
         b = x.shape[0]
         # conditioning: sinusoid -> Linear -> GELU -> Linear; label_proj; LN over the 2 tokens (denoiser.py:105-122)
@@ -132,3 +136,32 @@ class TorchRefDenoiser:
         x0[:, 3] += sharp_f                                                           # :88-89
         x0[:, 0] += bright_f
         return x0
+
+
+def train_step_reference(cfg, state_dict: Dict[str, np.ndarray], x: torch.Tensor, noise_level: torch.Tensor, noise: torch.Tensor,
+                         label: torch.Tensor, drop_mask: torch.Tensor):
+    """One optimisation step's forward + backward as the reference's training loop does it (tld/train.py:124-138,162-168), in fp32
+    with torch.autograd over the restated graph:
+
+        x_noisy = noise_level * noise + (1 - noise_level) * x          (:124-130)
+        label[drop_mask] = 0                                           (:136-138)
+        pred = model(x_noisy, noise_level.view(-1, 1), label)          (:166)
+        loss = MSELoss(pred, x); loss.backward()                       (:167-169)
+
+    Returns (loss, pred, {key: grad}) for every floating-point entry of the state_dict except the sinusoid buffer.
+    Test infrastructure (oracle of the native training engine); pinned against the reference's own autograd in g15."""
+    ref = TorchRefDenoiser(cfg, state_dict)
+    params = {}
+    for k, v in ref.w.items():
+        if v.is_floating_point() and "angular_speeds" not in k:
+            ref.w[k] = v.clone().requires_grad_(True)
+            params[k] = ref.w[k]
+    nl = noise_level.to(torch.float32)
+    x_noisy = (nl.view(-1, 1, 1, 1) * noise + (1 - nl).view(-1, 1, 1, 1) * x).float()
+    lab = label.clone()
+    lab[drop_mask] = 0
+    with torch.enable_grad():
+        pred = ref.forward_graph(x_noisy, nl.view(-1, 1), lab)
+        loss = F.mse_loss(pred, x)
+        grads = torch.autograd.grad(loss, list(params.values()))
+    return float(loss.detach()), pred.detach(), {k: g for k, g in zip(params.keys(), grads)}

@@ -1,0 +1,217 @@
+"""GPU: the native training step (tld/train.py:118-175) through the C ABI (tld_train_*).
+
+Oracles: g15 (the reference's own loss.backward() / Adam / EMA on the tiny model, captured by import) and, at the 100 M width, autograd
+over the pinned restatement (oracle/torch_ref.train_step_reference) run on the host in the test.
+Tolerances (bf16 GEMM operands and saved activations, fp32 accumulation / statistics / optimizer): loss 5e-3 relative, prediction
+FWD_TOL (2e-2) rel-rms, every parameter gradient GRAD_TOL = 2e-2 relative L2 -- with one stated exception, tensors whose gradient is
+dominated by cancellation noise (norm below 1e-3 of the largest tensor gradient) are held to GRAD_TOL of that largest norm instead."""
+import ctypes as C
+import os
+import subprocess
+import sys
+from dataclasses import asdict
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import cfg_from_arr, load_golden, rel_rms, synth_weights
+from test_gpu_parity import FWD_TOL, _dev
+
+pytestmark = pytest.mark.gpu
+
+GRAD_TOL = 2e-2
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _trainer(cfg, sd, **kw):
+    from transformer_latent_diffusion_amd import Trainer
+    return Trainer(cfg, device=_dev(), state_dict={k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, **kw)
+
+
+def _check_grads(got, want, tag):
+    norms = {k: float(np.linalg.norm(want[k])) for k in want}
+    big = max(norms.values())
+    worst = ("", 0.0)
+    for k in want:
+        err = float(np.linalg.norm(got[k] - want[k]))
+        rel = err / max(norms[k], 1e-3 * big)
+        if rel > worst[1]:
+            worst = (k, rel)
+        assert rel <= GRAD_TOL, (tag, k, rel, norms[k], big)
+    print(f"{tag}: worst gradient relative L2 {worst[1]:.2e} ({worst[0]})")
+
+
+def _g15():
+    g = load_golden("g15_train_step.npz")
+    cfg = cfg_from_arr(g["cfg"])
+    return g, cfg, synth_weights(cfg, g["weight_seed"], g["weight_checksum"])
+
+
+def test_forward_backward_vs_reference_step():
+    from transformer_latent_diffusion_amd.train import drop_labels, mix_noise
+    g, cfg, sd = _g15()
+    tr = _trainer(cfg, sd, max_batch=4)
+    x = torch.from_numpy(g["x"])
+    xn = mix_noise(x, torch.from_numpy(g["noise_level"]), torch.from_numpy(g["noise"]))
+    lab = drop_labels(torch.from_numpy(g["y"]), torch.from_numpy(g["mask"]))
+    loss, pred = tr.forward_backward(xn, torch.from_numpy(g["noise_level"]).float(), lab, x)
+    assert abs(float(loss) - float(g["loss"])) <= 5e-3 * float(g["loss"]), (float(loss), float(g["loss"]))
+    assert rel_rms(pred.cpu().numpy(), g["pred"]) <= FWD_TOL
+    got = {k: v.cpu().numpy() for k, v in tr.grad_dict().items()}
+    _check_grads(got, {k: g["grad:" + k] for k in got}, "tiny model vs g15")
+    # bit-reproducible: the same call again leaves the same gradient vector
+    first = tr.grads.clone()
+    tr.forward_backward(xn, torch.from_numpy(g["noise_level"]).float(), lab, x)
+    assert torch.equal(first, tr.grads)
+
+
+def test_adam_and_ema_kernel_vs_reference_update():
+    """The fused optimizer kernel on the REFERENCE's gradients: post-step weights and EMA weights of the fixture (torch.optim.Adam lr 3e-4,
+    update_ema alpha 0.999), <= 2e-7 absolute; then a second step against torch.optim.Adam run on the host."""
+    g, cfg, sd = _g15()
+    from transformer_latent_diffusion_amd import TrainConfig
+    tr = _trainer(cfg, sd, max_batch=4, train_cfg=TrainConfig(lr=float(g["lr"]), alpha=float(g["alpha"])))
+    host_g = torch.zeros(tr.numel)
+    for k, (o, s) in tr.layout.items():
+        host_g[o:o + int(np.prod(s))] = torch.from_numpy(g["grad:" + k]).reshape(-1)
+    p0 = tr.params.cpu().clone()
+    tr.grads.copy_(host_g)
+    tr.optimizer_step()
+    new, ema = tr.state_dict(), tr.ema_state_dict()
+    for k in [k[4:] for k in g if k.startswith("new:")]:
+        assert np.abs(new[k].cpu().numpy() - g["new:" + k]).max() <= 2e-7, k
+        assert np.abs(ema[k].cpu().numpy() - g["ema:" + k]).max() <= 2e-7, k
+    # second step, whole vector, against torch.optim.Adam + the EMA statement on the host
+    w = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([w], lr=float(g["lr"]))
+    e = p0.clone()
+    g2 = torch.randn(tr.numel, generator=torch.Generator().manual_seed(4)) * 1e-2
+    for gg in (host_g, g2):
+        w.grad = gg.clone(); opt.step()
+        e.mul_(float(g["alpha"])).add_(w.detach(), alpha=1 - float(g["alpha"]))
+    tr.grads.copy_(g2)
+    tr.optimizer_step()
+    assert (tr.params.cpu() - w.detach()).abs().max() <= 5e-7
+    assert (tr.ema.cpu() - e).abs().max() <= 5e-7
+    assert tr.step == 2 and tr.checkpoint()["global_step"] == 2
+
+
+def test_attention_backward_vs_autograd():
+    """tld_debug_attention_bwd against torch autograd of softmax(q k^T / 8) v on the same bf16-rounded operands: dq, dk, dv <= 2e-2."""
+    from transformer_latent_diffusion_amd import _lib
+    B, H, N = 3, 2, 256
+    d = 64 * H
+    gen = torch.Generator().manual_seed(9)
+    q, k, v = (torch.randn(B, N, d, generator=gen).bfloat16().float() for _ in range(3))
+    q = q * 1.5
+    go = torch.randn(B, N, d, generator=gen) * 0.1
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    sp = lambda t: t.view(B, N, H, 64).transpose(1, 2)
+    o = torch.nn.functional.scaled_dot_product_attention(sp(qr), sp(kr), sp(vr)).transpose(1, 2).reshape(B, N, d)
+    o.backward(go)
+    dev = _dev()
+    qk = torch.cat([q, k], dim=-1).bfloat16().to(dev).contiguous()
+    vt = v.view(B, N, H, 64).permute(0, 2, 3, 1).contiguous().bfloat16().to(dev)            # [B, H, 64, N]
+    ob = o.detach().bfloat16().to(dev).contiguous()
+    gd = go.to(dev).contiguous()
+    out = torch.zeros(B * N, 3 * d, dtype=torch.bfloat16, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.lib().tld_debug_attention_bwd(C.c_void_p(qk.data_ptr()), C.c_void_p(vt.data_ptr()), C.c_void_p(ob.data_ptr()),
+                                                  C.c_void_p(gd.data_ptr()), C.c_void_p(out.data_ptr()), B, H, st), "attention_bwd")
+    got = out.float().cpu().view(B, N, 3, d)
+    for i, (name, ref) in enumerate((("dq", qr.grad), ("dk", kr.grad), ("dv", vr.grad))):
+        e = rel_rms(got[:, :, i].numpy(), ref.numpy())
+        print(f"attention backward {name}: rel-rms {e:.2e}")
+        assert e <= 2e-2, (name, e)
+
+
+def test_wide_model_gradients_vs_oracle_autograd():
+    """100 M-class width (d = 768, 12 heads, hidden 3072), 2 blocks, B = 3: every gradient vs autograd over the pinned restatement."""
+    from oracle.torch_ref import train_step_reference
+    from transformer_latent_diffusion_amd import DenoiserConfig
+    from transformer_latent_diffusion_amd.train import drop_labels, mix_noise
+    from transformer_latent_diffusion_amd.weights import synth_state_dict
+    cfg = DenoiserConfig(image_size=32, noise_embed_dims=256, patch_size=2, embed_dim=768, dropout=0, n_layers=2, text_emb_size=768, n_channels=4,
+                         mlp_multiplier=4)
+    sd = synth_state_dict(cfg, 31)
+    gen = torch.Generator().manual_seed(32)
+    B = 3
+    x = torch.randn(B, 4, 32, 32, generator=gen) * 0.8
+    y = torch.randn(B, 768, generator=gen) * 0.5
+    nl = torch.tensor([0.07, 0.45, 0.9], dtype=torch.float64)
+    noise = torch.randn(B, 4, 32, 32, generator=gen)
+    mask = torch.tensor([False, False, True])
+    loss_ref, pred_ref, grads_ref = train_step_reference(cfg, sd, x, nl, noise, y, mask)
+    tr = _trainer(cfg, sd, max_batch=4)
+    loss, pred = tr.forward_backward(mix_noise(x, nl, noise), nl.float(), drop_labels(y, mask), x)
+    assert abs(float(loss) - loss_ref) <= 5e-3 * loss_ref, (float(loss), loss_ref)
+    assert rel_rms(pred.cpu().numpy(), pred_ref.numpy()) <= FWD_TOL
+    got = {k: v.cpu().numpy() for k, v in tr.grad_dict().items()}
+    _check_grads(got, {k: grads_ref[k].numpy() for k in got}, "d = 768, 2 blocks vs oracle autograd")
+
+
+def test_training_reduces_the_loss_and_ema_loads_into_the_inference_engine():
+    """A few steps of Trainer.train_step on a fixed batch: the loss goes down; the EMA state_dict loads into the inference Denoiser."""
+    from transformer_latent_diffusion_amd import Denoiser, DenoiserConfig, TrainConfig, Trainer
+    cfg = DenoiserConfig(image_size=32, n_channels=4)
+    tr = Trainer(cfg, TrainConfig(lr=1e-3, alpha=0.9), device=_dev(), init_seed=2, max_batch=8)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(8, 4, 32, 32, generator=gen) * 0.8
+    y = torch.randn(8, 768, generator=gen) * 0.5
+    losses = []
+    for i in range(12):
+        rng, tg = np.random.default_rng(0), torch.Generator().manual_seed(0)          # the same noise every step: a fixed objective
+        losses.append(float(tr.train_step(x, y, np_rng=rng, generator=tg)))
+    assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], losses
+    m = Denoiser(**asdict(cfg)).to(_dev())
+    m.load_state_dict(tr.ema_state_dict())
+    out = m(x[:2].to(_dev()), torch.full((2, 1), 0.5, device=_dev()), y[:2].to(_dev()))
+    assert out.shape == (2, 4, 32, 32) and torch.isfinite(out).all()
+
+
+_RANK = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r})
+from transformer_latent_diffusion_amd import DenoiserConfig, TrainConfig, Trainer
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+cfg = DenoiserConfig(image_size=32, n_channels=4)
+tr = Trainer(cfg, TrainConfig(lr=3e-4), device=dev, init_seed=3, max_batch=4)
+g = torch.Generator().manual_seed(7)
+x = torch.randn(4, 4, 32, 32, generator=g) * 0.8; y = torch.randn(4, 768, generator=g) * 0.5
+nl = torch.tensor([0.1, 0.3, 0.6, 0.8]); noise = torch.randn(4, 4, 32, 32, generator=g)
+xn = nl.view(-1, 1, 1, 1) * noise + (1 - nl.view(-1, 1, 1, 1)) * x
+sl = slice(r * 4 // w, (r + 1) * 4 // w)
+tr.forward_backward(xn[sl], nl[sl], y[sl], x[sl])
+# gloo moves device tensors through the host; RCCL ("nccl") is what a multi-GPU node uses -- same call
+tr.optimizer_step()
+torch.save(tr.params.cpu(), {out!r} + f".{{w}}.{{r}}")
+print("rank", r, "done")
+"""
+
+
+def test_two_ranks_average_gradients_like_one_process(tmp_path):
+    """DDP semantics of the step: two ranks (both on this GPU, gloo collectives) each take half of a batch; after the all-reduce + Adam
+    step both hold the same parameters, and those equal a single process stepping on the whole batch (the loss is a mean over equally
+    sized shards) up to summation order."""
+    script = tmp_path / "rank.py"
+    out = str(tmp_path / "params")
+    script.write_text(_RANK.format(repo=REPO, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for w in (2, 1):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={w}", "--master-addr", "127.0.0.1",
+                            "--master-port", "29563", str(script)], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    a, b, one = torch.load(out + ".2.0"), torch.load(out + ".2.1"), torch.load(out + ".1.0")
+    assert torch.equal(a, b)
+    # Adam's first step moves every weight by ~lr * sign(g): compare the UPDATE directions where the gradient is not at noise level
+    base = torch.cat([torch.from_numpy(np.array(v)).reshape(-1) for k, v in __import__("transformer_latent_diffusion_amd").weights.synth_state_dict(
+        __import__("transformer_latent_diffusion_amd").DenoiserConfig(image_size=32, n_channels=4), 3).items()
+        if "angular" not in k and "precomputed" not in k])
+    da, d1 = a - base, one - base
+    agree = (torch.sign(da) == torch.sign(d1)).float().mean().item()
+    assert agree > 0.97, agree
+    assert (da - d1).abs().max() <= 2 * 3e-4 + 1e-7

@@ -1,0 +1,463 @@
+// tld_train.hip -- the training step of the denoiser on gfx950: C ABI tld_train_*.
+//
+// Replaces, for one optimisation step of tld/train.py:162-173,
+//     pred = model(x_noisy, noise_level.view(-1, 1), label); loss = MSELoss(pred, x); loss.backward()      -> tld_train_forward_backward
+//     optimizer.step() (torch.optim.Adam) + update_ema(ema_model, model, alpha)  (tld/train.py:55-58)       -> tld_train_adam_ema
+// The gradient all-reduce of accelerate's DDP wrapper stays with the caller (torch.distributed over RCCL on the flat gradient buffer,
+// transformer_latent_diffusion_amd/train.py): parameters, gradients, Adam moments and the EMA copy are FLAT fp32 device buffers
+// owned by the caller in the canonical order of Denoiser.named_parameters() (tld_train_param_layout).
+//
+// Arithmetic: fp32 master parameters; the big projections (QKV, cross-attention Q, MLP up / down) and their dX / dW products are
+// bf16-operand, fp32-accumulate MFMA GEMMs (tld_gemm.hip); activations that are saved for the backward are bf16; LayerNorm, softmax,
+// GELU, the conditioning path, the patch embedding, reductions and the optimizer are fp32.  The training forward is the plain module
+// graph (none of the inference path's algebraic folds), so every saved tensor is the one autograd would save.
+#include "../../include/tld_hip.h"
+#include "tld_train_kernels.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace tld;
+using namespace tld::train;
+
+namespace tld {
+int launch_attention_bwd(const bf16* qk, const bf16* vt, const bf16* o, const float* g, bf16* dqkv, int batch, int ntok, int heads, hipStream_t s);
+}
+
+namespace {
+
+int tfail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    tld::set_last_error(buf);
+    return code;
+}
+#define HIP_TRY(expr)                                                                                                            \
+    do {                                                                                                                         \
+        hipError_t _e = (expr);                                                                                                  \
+        if (_e != hipSuccess) return tfail(TLD_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevGuard {
+    int prev = -1; bool switched = false;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+struct Tensor { std::string key; int64_t off, numel; };
+
+struct LayerP {          // offsets into the flat parameter / gradient vectors
+    int64_t qkv, kv, q, up_w, up_b, dw_w, dw_b, down_w, down_b, n1w, n1b, n2w, n2b, n3w, n3b;
+};
+struct LayerB {          // engine-owned per-layer buffers
+    bf16 *wqkv, *wqkv_t, *wq, *wq_t, *wup, *wup_t, *wdown, *wdown_t;          // bf16 GEMM operands and their transposes
+    bf16 *x1, *x2, *x3;                                                      // residual stream at the input of the three sub-blocks
+    float2 *st1, *st2, *st3;
+    bf16 *a1, *a2, *a3, *qk, *vt, *att, *qc, *cr, *h, *hc, *gl, *o;
+    float *kvc, *p0;
+};
+
+inline dim3 g1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+struct tld_train {
+    tld_config cfg{};
+    int d = 0, L = 0, H = 0, N = 0, G = 0, pd = 0, hid = 0, S = 0, C = 0, ne = 0, text = 0, B = 0;
+    std::vector<Tensor> layout;
+    int64_t nparam = 0;
+    // offsets of the non-layer tensors
+    int64_t ff1w, ff1b, ff3w, ff3b, cvw, cvb, l1w, l1b, liw, lib, l2w, l2b, pos, outw, outb, nw, nb, lbw, lbb;
+    std::vector<LayerP> lp;
+    std::vector<LayerB> lb;
+    float *params = nullptr, *grads = nullptr;
+    std::vector<void*> allocs;
+    float* angular = nullptr;            // sinusoid buffer (not a parameter; tld/transformer_blocks.py:11-15)
+    float* zero_bias = nullptr;
+    // conditioning path
+    float *sinb, *h1, *g1v, *ycat, *y, *dy, *dycat, *dg1, *dkv;
+    float2* yst;
+    // embedding
+    float *p16, *p16n, *e, *patches, *de, *dpn, *dp16;
+    float2 *est1, *est2;
+    bf16* xfin;
+    // tail / loss
+    float *dout, *row_loss, *io;
+    // backward scratch
+    float* gx;                           // dL/d(residual stream) fp32 [M, d]
+    bf16 *gxb, *T1, *T2, *dbig, *dsmall, *dsmall2;
+    float* scr;                          // small fp32 scratch ([pd, d])
+    float* part;                         // reduction partials
+    size_t part_floats = 0;
+    bool weights_fresh = false;
+};
+
+namespace {
+
+void add_t(tld_train* e, const std::string& k, int64_t n, int64_t* off) {
+    *off = e->nparam;
+    e->layout.push_back({k, e->nparam, n});
+    e->nparam += n;
+}
+
+template <typename T>
+int dalloc(tld_train* e, T** p, size_t n) {
+    void* q = nullptr;
+    if (hipMalloc(&q, n * sizeof(T)) != hipSuccess) return tfail(TLD_ERR_HIP, "hipMalloc of %zu bytes failed", n * sizeof(T));
+    e->allocs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return 0;
+}
+#define DALLOC(ptr, n) do { int _r = dalloc(e, &(ptr), (size_t)(n)); if (_r) return _r; } while (0)
+
+// C[Mr, Nc] = A[Mr, K] . W[Nc, K]^T on the engine's MFMA GEMM
+void gemm_f32(const bf16* A, int lda, const bf16* W, int ldw, float* C, int Mr, int Nc, int K, hipStream_t s) {
+    GemmParams g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = Mr; g.N = Nc; g.K = K; g.c_f32 = C; g.ldc = Nc;
+    launch_gemm(g, EPI_F32, s);
+}
+void gemm_bf16(const bf16* A, int lda, const bf16* W, int ldw, const float* bias, bf16* out, int Mr, int Nc, int K, hipStream_t s) {
+    GemmParams g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = Mr; g.N = Nc; g.K = K; g.out_bf16 = out; g.ldo = Nc; g.bias = bias;
+    launch_gemm(g, EPI_BIAS_BF16, s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tld_train_create(const tld_config* cfg, tld_train** out) {
+    if (!cfg || !out) return tfail(TLD_ERR_INVALID, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return tfail(TLD_ERR_HIP, "no HIP device: the training engine has no CPU path");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return tfail(TLD_ERR_INVALID, "device_id %d out of range", cfg->device_id);
+    if (cfg->embed_dim % 128 || cfg->embed_dim > 1024 || cfg->embed_dim <= 0) return tfail(TLD_ERR_INVALID, "embed_dim must be a multiple of 128, <= 1024");
+    if (cfg->patch_size <= 0 || cfg->image_size % cfg->patch_size) return tfail(TLD_ERR_INVALID, "image_size must be a multiple of patch_size");
+    const int G = cfg->image_size / cfg->patch_size;
+    if (G * G != 256) return tfail(TLD_ERR_INVALID, "the training step is built for 256-token latents (image_size / patch_size = 16); got %d tokens", G * G);
+    if (cfg->n_channels * cfg->patch_size * cfg->patch_size > 64) return tfail(TLD_ERR_INVALID, "patch_dim must be <= 64");
+    if (cfg->noise_embed_dims % 2 || cfg->max_batch <= 0 || cfg->n_layers <= 0) return tfail(TLD_ERR_INVALID, "bad configuration");
+    DevGuard dg(cfg->device_id);
+    tld_train* e = new tld_train();
+    e->cfg = *cfg;
+    e->d = cfg->embed_dim; e->L = cfg->n_layers; e->H = e->d / 64; e->G = G; e->N = G * G; e->S = cfg->image_size; e->C = cfg->n_channels;
+    e->pd = e->C * cfg->patch_size * cfg->patch_size; e->hid = e->d * cfg->mlp_multiplier; e->ne = cfg->noise_embed_dims; e->text = cfg->text_emb_size;
+    e->B = cfg->max_batch;
+    const int d = e->d, hid = e->hid, pd = e->pd;
+    // canonical order: Denoiser.named_parameters() of the reference (tld/denoiser.py:85-114; pinned by tests/test_train_host.py)
+    add_t(e, "fourier_feats.1.weight", (int64_t)d * e->ne, &e->ff1w); add_t(e, "fourier_feats.1.bias", d, &e->ff1b);
+    add_t(e, "fourier_feats.3.weight", (int64_t)d * d, &e->ff3w); add_t(e, "fourier_feats.3.bias", d, &e->ff3b);
+    const std::string blk = "denoiser_trans_block.";
+    add_t(e, blk + "patchify_and_embed.0.weight", (int64_t)pd * pd, &e->cvw); add_t(e, blk + "patchify_and_embed.0.bias", pd, &e->cvb);
+    add_t(e, blk + "patchify_and_embed.2.weight", pd, &e->l1w); add_t(e, blk + "patchify_and_embed.2.bias", pd, &e->l1b);
+    add_t(e, blk + "patchify_and_embed.3.weight", (int64_t)d * pd, &e->liw); add_t(e, blk + "patchify_and_embed.3.bias", d, &e->lib);
+    add_t(e, blk + "patchify_and_embed.4.weight", d, &e->l2w); add_t(e, blk + "patchify_and_embed.4.bias", d, &e->l2b);
+    add_t(e, blk + "pos_embed.weight", (int64_t)e->N * d, &e->pos);
+    e->lp.resize(e->L);
+    for (int i = 0; i < e->L; ++i) {
+        const std::string p = blk + "decoder_blocks." + std::to_string(i) + ".";
+        LayerP& q = e->lp[i];
+        add_t(e, p + "self_attention.qkv_linear.weight", (int64_t)3 * d * d, &q.qkv);
+        add_t(e, p + "cross_attention.kv_linear.weight", (int64_t)2 * d * d, &q.kv);
+        add_t(e, p + "cross_attention.q_linear.weight", (int64_t)d * d, &q.q);
+        add_t(e, p + "mlp.mlp.0.weight", (int64_t)hid * d, &q.up_w); add_t(e, p + "mlp.mlp.0.bias", hid, &q.up_b);
+        add_t(e, p + "mlp.mlp.1.weight", (int64_t)hid * 9, &q.dw_w); add_t(e, p + "mlp.mlp.1.bias", hid, &q.dw_b);
+        add_t(e, p + "mlp.mlp.3.weight", (int64_t)d * hid, &q.down_w); add_t(e, p + "mlp.mlp.3.bias", d, &q.down_b);
+        add_t(e, p + "norm1.weight", d, &q.n1w); add_t(e, p + "norm1.bias", d, &q.n1b);
+        add_t(e, p + "norm2.weight", d, &q.n2w); add_t(e, p + "norm2.bias", d, &q.n2b);
+        add_t(e, p + "norm3.weight", d, &q.n3w); add_t(e, p + "norm3.bias", d, &q.n3b);
+    }
+    add_t(e, blk + "out_proj.0.weight", (int64_t)pd * d, &e->outw); add_t(e, blk + "out_proj.0.bias", pd, &e->outb);
+    add_t(e, "norm.weight", d, &e->nw); add_t(e, "norm.bias", d, &e->nb);
+    add_t(e, "label_proj.weight", (int64_t)d * e->text, &e->lbw); add_t(e, "label_proj.bias", d, &e->lbb);
+
+    const size_t B = e->B, M = B * e->N;
+    if (M * (size_t)hid * 2 >= ((size_t)1 << 32)) { delete e; return tfail(TLD_ERR_INVALID, "max_batch too large: the MLP hidden activation must stay below 4 GiB"); }
+    auto cleanup = [&](int rc) { for (void* p : e->allocs) hipFree(p); delete e; return rc; };
+    auto alloc_all = [&]() -> int {
+        DALLOC(e->angular, e->ne / 2); DALLOC(e->zero_bias, 3 * hid > 4096 ? 3 * hid : 4096);
+        DALLOC(e->sinb, B * e->ne); DALLOC(e->h1, B * d); DALLOC(e->g1v, B * d); DALLOC(e->ycat, B * 2 * d); DALLOC(e->y, B * 2 * d);
+        DALLOC(e->dy, B * 2 * d); DALLOC(e->dycat, B * 2 * d); DALLOC(e->dg1, B * d); DALLOC(e->dkv, B * 2 * 2 * d); DALLOC(e->yst, B * 2);
+        DALLOC(e->p16, M * pd); DALLOC(e->p16n, M * pd); DALLOC(e->e, M * d); DALLOC(e->patches, M * pd); DALLOC(e->de, M * d);
+        DALLOC(e->dpn, M * pd); DALLOC(e->dp16, M * pd); DALLOC(e->est1, M); DALLOC(e->est2, M); DALLOC(e->xfin, M * d);
+        DALLOC(e->dout, M * pd); DALLOC(e->row_loss, M); DALLOC(e->io, 4);
+        const size_t wide = hid > 3 * d ? hid : 3 * d;
+        DALLOC(e->gx, M * d); DALLOC(e->gxb, M * d); DALLOC(e->T1, M * wide); DALLOC(e->T2, M * wide); DALLOC(e->dbig, M * hid);
+        DALLOC(e->dsmall, M * 3 * d); DALLOC(e->dsmall2, M * d); DALLOC(e->scr, (size_t)pd * d + 64);
+        const size_t nchunk = (M + 255) / 256;
+        size_t need = nchunk * 2 * (size_t)wide;                              // LN / colsum partials
+        if (B * 10 * (size_t)hid > need) need = B * 10 * (size_t)hid;          // depthwise weight-gradient partials
+        if (nchunk * (size_t)pd * d > need) need = nchunk * (size_t)pd * d;    // tall weight-gradient partials
+        e->part_floats = need;
+        DALLOC(e->part, need);
+        e->lb.resize(e->L);
+        for (int i = 0; i < e->L; ++i) {
+            LayerB& q = e->lb[i];
+            DALLOC(q.wqkv, 3 * d * d); DALLOC(q.wqkv_t, 3 * d * d); DALLOC(q.wq, d * d); DALLOC(q.wq_t, d * d);
+            DALLOC(q.wup, hid * d); DALLOC(q.wup_t, hid * d); DALLOC(q.wdown, hid * d); DALLOC(q.wdown_t, hid * d);
+            DALLOC(q.x1, M * d); DALLOC(q.x2, M * d); DALLOC(q.x3, M * d); DALLOC(q.st1, M); DALLOC(q.st2, M); DALLOC(q.st3, M);
+            DALLOC(q.a1, M * d); DALLOC(q.a2, M * d); DALLOC(q.a3, M * d); DALLOC(q.qk, M * 2 * d); DALLOC(q.vt, M * d); DALLOC(q.att, M * d);
+            DALLOC(q.qc, M * d); DALLOC(q.cr, M * d); DALLOC(q.h, M * hid); DALLOC(q.hc, M * hid); DALLOC(q.gl, M * hid); DALLOC(q.o, M * d);
+            DALLOC(q.kvc, B * 2 * 2 * d); DALLOC(q.p0, M * e->H);
+        }
+        return 0;
+    };
+    if (int rc = alloc_all()) return cleanup(rc);
+    if (hipMemset(e->zero_bias, 0, (size_t)(3 * hid > 4096 ? 3 * hid : 4096) * 4) != hipSuccess) return cleanup(tfail(TLD_ERR_HIP, "hipMemset failed"));
+    // angular_speeds = 2 pi exp(linspace(log 1, log 1000, ne / 2))   (tld/transformer_blocks.py:11-15; float32 arithmetic as torch does it)
+    {
+        const int half = e->ne / 2;
+        std::vector<float> a(half);
+        const float lo = logf(1.0f), hiv = logf(1000.0f);
+        const float step = half > 1 ? (hiv - lo) / (float)(half - 1) : 0.f;
+        for (int k = 0; k < half; ++k) {
+            // torch.linspace fills the upper half from the end (hi - step * (n - 1 - k)) for symmetry
+            const float v = k < half / 2 ? lo + step * (float)k : hiv - step * (float)(half - 1 - k);
+            a[k] = 2.0f * 3.14159265358979323846f * expf(v);
+        }
+        if (hipMemcpy(e->angular, a.data(), half * 4, hipMemcpyHostToDevice) != hipSuccess) return cleanup(tfail(TLD_ERR_HIP, "hipMemcpy failed"));
+    }
+    *out = e;
+    return TLD_OK;
+}
+
+int64_t tld_train_param_count(const tld_train* e) { return e ? e->nparam : 0; }
+int32_t tld_train_tensor_count(const tld_train* e) { return e ? (int32_t)e->layout.size() : 0; }
+
+int tld_train_param_layout(const tld_train* e, int32_t index, char* key_out, int32_t key_cap, int64_t* offset, int64_t* numel) {
+    if (!e || index < 0 || index >= (int32_t)e->layout.size() || !key_out || key_cap <= 0) return tfail(TLD_ERR_INVALID, "bad argument");
+    const Tensor& t = e->layout[index];
+    snprintf(key_out, (size_t)key_cap, "%s", t.key.c_str());
+    if (offset) *offset = t.off;
+    if (numel) *numel = t.numel;
+    return TLD_OK;
+}
+
+/* The sinusoid buffer "fourier_feats.0.angular_speeds" is a registered buffer of the reference, not a parameter; a checkpoint's
+ * values can be installed here (host fp32 [noise_embed_dims / 2]); the default is the constructor's formula. */
+int tld_train_set_angular_speeds(tld_train* e, const float* host, int32_t n) {
+    if (!e || !host || n != e->ne / 2) return tfail(TLD_ERR_SHAPE, "angular_speeds must have %d entries", e ? e->ne / 2 : 0);
+    DevGuard dg(e->cfg.device_id);
+    HIP_TRY(hipMemcpy(e->angular, host, (size_t)n * 4, hipMemcpyHostToDevice));
+    return TLD_OK;
+}
+
+int tld_train_bind(tld_train* e, float* params, float* grads) {
+    if (!e || !params || !grads) return tfail(TLD_ERR_INVALID, "null argument");
+    e->params = params; e->grads = grads; e->weights_fresh = false;
+    return TLD_OK;
+}
+
+int tld_train_refresh_weights(tld_train* e, void* hip_stream) {
+    if (!e || !e->params) return tfail(TLD_ERR_STATE, "tld_train_bind first");
+    DevGuard dg(e->cfg.device_id);
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    const int d = e->d, hid = e->hid;
+    auto both = [&](int64_t off, int R, int Cc, bf16* w, bf16* wt) {       // [R, C] fp32 -> bf16 copy and bf16 transpose [C, R]
+        hipLaunchKernelGGL(cast_f32_bf16, g1((size_t)R * Cc), dim3(256), 0, s, e->params + off, w, (size_t)R * Cc);
+        hipLaunchKernelGGL((transpose_to_bf16<float>), dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, e->params + off, Cc, wt, R, R, Cc);
+    };
+    for (int i = 0; i < e->L; ++i) {
+        both(e->lp[i].qkv, 3 * d, d, e->lb[i].wqkv, e->lb[i].wqkv_t);
+        both(e->lp[i].q, d, d, e->lb[i].wq, e->lb[i].wq_t);
+        both(e->lp[i].up_w, hid, d, e->lb[i].wup, e->lb[i].wup_t);
+        both(e->lp[i].down_w, d, hid, e->lb[i].wdown, e->lb[i].wdown_t);
+    }
+    HIP_TRY(hipGetLastError());
+    e->weights_fresh = true;
+    return TLD_OK;
+}
+
+int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* noise_level, const float* label, const float* target,
+                               int32_t batch, float* loss_out, float* pred_out, void* hip_stream) {
+    if (!e || !x_noisy || !noise_level || !label || !target || !loss_out || !pred_out) return tfail(TLD_ERR_INVALID, "null argument");
+    if (!e->params) return tfail(TLD_ERR_STATE, "tld_train_bind first");
+    if (batch <= 0 || batch > e->B) return tfail(TLD_ERR_INVALID, "batch %d outside [1, max_batch = %d]", batch, e->B);
+    DevGuard dg(e->cfg.device_id);
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    if (!e->weights_fresh) { if (int rc = tld_train_refresh_weights(e, hip_stream)) return rc; }
+    const int d = e->d, hid = e->hid, pd = e->pd, N = e->N, H = e->H, B = batch, M = B * N, G = e->G;
+    float* P = e->params; float* Gd = e->grads;
+    const dim3 blk(256);
+    const int nchunk = (M + 255) / 256;
+    const float inv_numel = 1.0f / (float)((size_t)B * e->C * e->S * e->S);
+
+    // ================================================ forward ================================================
+    // conditioning (tld/denoiser.py:105-122): sinusoid -> Linear -> GELU -> Linear | label_proj -> stack -> LayerNorm
+    hipLaunchKernelGGL(sinusoid_kernel, g1((size_t)B * e->ne / 2), blk, 0, s, noise_level, e->angular, e->sinb, B, e->ne / 2);
+    hipLaunchKernelGGL(small_linear_fwd, g1((size_t)B * d), blk, 0, s, e->sinb, e->ne, P + e->ff1w, P + e->ff1b, e->g1v, d, B, d, e->ne, e->h1, 1);
+    hipLaunchKernelGGL(small_linear_fwd, g1((size_t)B * d), blk, 0, s, e->g1v, d, P + e->ff3w, P + e->ff3b, e->ycat, 2 * d, B, d, d, (float*)nullptr, 0);
+    hipLaunchKernelGGL(small_linear_fwd, g1((size_t)B * d), blk, 0, s, label, e->text, P + e->lbw, P + e->lbb, e->ycat + d, 2 * d, B, d, e->text, (float*)nullptr, 0);
+    hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3((2 * B + 3) / 4), blk, 0, s, e->ycat, P + e->nw, P + e->nb, (bf16*)nullptr, e->y, e->yst,
+                       (const float*)nullptr, 1, 2 * B, d);
+    // patch embedding (tld/denoiser.py:34-45,75-77)
+    {
+        EmbedTrain q{};
+        q.x = x_noisy; q.conv_w = P + e->cvw; q.conv_b = P + e->cvb; q.ln1_w = P + e->l1w; q.ln1_b = P + e->l1b; q.lin_w = P + e->liw; q.lin_b = P + e->lib;
+        q.ln2_w = P + e->l2w; q.ln2_b = P + e->l2b; q.pos = P + e->pos; q.p = e->p16; q.pn = e->p16n; q.st1 = e->est1; q.e = e->e; q.st2 = e->est2;
+        q.x0 = e->lb[0].x1; q.B = B; q.C = e->C; q.S = e->S; q.patch = e->cfg.patch_size; q.grid = G; q.pd = pd; q.d = d;
+        hipLaunchKernelGGL(embed_fwd_kernel, dim3((M + 3) / 4), blk, 0, s, q);
+    }
+    for (int i = 0; i < e->L; ++i) {
+        LayerB& b = e->lb[i]; const LayerP& p = e->lp[i];
+        // x = x + SA(LN1 x)   (tld/transformer_blocks.py:51-59,136)
+        hipLaunchKernelGGL((ln_fwd_kernel<bf16>), dim3((M + 3) / 4), blk, 0, s, b.x1, P + p.n1w, P + p.n1b, b.a1, (float*)nullptr, b.st1, (const float*)nullptr, 1, M, d);
+        {
+            GemmParams g{};
+            g.A = b.a1; g.lda = d; g.W = b.wqkv; g.ldw = d; g.M = M; g.N = 3 * d; g.K = d; g.out_bf16 = b.qk; g.ldo = 2 * d; g.vt = b.vt; g.ntok = N; g.d = d;
+            launch_gemm(g, EPI_QKV, s);
+        }
+        launch_attention(b.qk, b.vt, b.att, B, N, H, s);
+        hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x1, b.att, b.x2, P + p.n2w, P + p.n2b, b.a2, b.st2, M, d);
+        // x = x + CA(LN2 x, y)   (:62-72,137)
+        gemm_bf16(b.a2, d, b.wq, d, e->zero_bias, b.qc, M, d, d, s);
+        hipLaunchKernelGGL(small_linear_fwd, g1((size_t)2 * B * 2 * d), blk, 0, s, e->y, d, P + p.kv, (const float*)nullptr, b.kvc, 2 * d, 2 * B, 2 * d, d, (float*)nullptr, 0);
+        hipLaunchKernelGGL(cross_fwd_kernel, dim3(B * H), blk, 0, s, b.qc, b.kvc, b.cr, b.p0, N, d);
+        hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x2, b.cr, b.x3, P + p.n3w, P + p.n3b, b.a3, b.st3, M, d);
+        // x = x + MLPSepConv(LN3 x)   (:89-113,138)
+        gemm_bf16(b.a3, d, b.wup, d, P + p.up_b, b.h, M, hid, d, s);
+        hipLaunchKernelGGL(dwconv_kernel, g1((size_t)M * hid), blk, 0, s, b.h, P + p.dw_w, P + p.dw_b, b.hc, b.gl, B, G, hid, 0);
+        gemm_bf16(b.gl, hid, b.wdown, hid, P + p.down_b, b.o, M, d, hid, s);
+        bf16* xnext = i + 1 < e->L ? e->lb[i + 1].x1 : e->xfin;
+        hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x3, b.o, xnext, (const float*)nullptr, (const float*)nullptr, (bf16*)nullptr, (float2*)nullptr, M, d);
+    }
+    // out_proj + unpatchify + MSE (tld/denoiser.py:47-52,72,82; tld/train.py:167)
+    hipLaunchKernelGGL(tail_fwd_kernel, dim3((M + 3) / 4), blk, 0, s, e->xfin, P + e->outw, P + e->outb, target, pred_out, e->dout, e->row_loss, B, e->C, e->S,
+                       e->cfg.patch_size, G, pd, d, inv_numel);
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), blk, 0, s, e->row_loss, M, inv_numel, loss_out);
+
+    // ================================================ backward ===============================================
+    auto reduce = [&](int nparts, size_t stride, size_t part_off, float* dst, int n, int acc) {
+        hipLaunchKernelGGL(reduce_partials, g1(n), blk, 0, s, e->part + part_off, nparts, stride, dst, n, acc);
+    };
+    auto ln_bwd_rows = [&](auto dyp, auto xp, const float2* st, const float* gamma, float* dx, int acc, float* dgamma, float* dbeta, int rows, int width) {
+        using TDY = std::remove_cv_t<std::remove_pointer_t<decltype(dyp)>>;
+        using TX = std::remove_cv_t<std::remove_pointer_t<decltype(xp)>>;
+        const int nb = (rows + 255) / 256;
+        hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 256, rows, width);
+        reduce(nb, 2 * (size_t)width, 0, dgamma, width, 0);
+        reduce(nb, 2 * (size_t)width, width, dbeta, width, 0);
+    };
+    auto colsum = [&](auto ap, int rows, int cols, float* dst) {
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(ap)>>;
+        const int nb = (rows + 255) / 256;
+        hipLaunchKernelGGL((colsum_partial<T>), dim3((cols + 255) / 256, nb), blk, 0, s, ap, rows, cols, 256, e->part);
+        reduce(nb, (size_t)cols, 0, dst, cols, 0);
+    };
+    auto transpose = [&](auto inp, int rows, int cols, bf16* outp) {        // [rows, cols] -> [cols, rows]
+        using T = std::remove_cv_t<std::remove_pointer_t<decltype(inp)>>;
+        hipLaunchKernelGGL((transpose_to_bf16<T>), dim3((cols + 31) / 32, (rows + 31) / 32), blk, 0, s, inp, cols, outp, rows, rows, cols);
+    };
+    // dW[Nout, Kin] = dY^T X with dY [M, Nout], X [M, Kin] (bf16): both operands transposed so that the contraction (M) is contiguous
+    auto weight_grad = [&](const bf16* dY, int Nout, const bf16* X, int Kin, float* dW) {
+        transpose(dY, M, Nout, e->T1);
+        transpose(X, M, Kin, e->T2);
+        gemm_f32(e->T1, M, e->T2, M, dW, Nout, Kin, M, s);
+    };
+
+    // out_proj: gx = dout Wout;  dWout = dout^T x_final;  dbout
+    hipLaunchKernelGGL(tail_dx_kernel, g1((size_t)M * d), blk, 0, s, e->dout, P + e->outw, e->gx, M, pd, d);
+    hipLaunchKernelGGL((tall_dw_partial<bf16>), dim3((pd * d + 255) / 256, nchunk), blk, 0, s, e->dout, pd, e->xfin, d, M, 256, e->part);
+    reduce(nchunk, (size_t)pd * d, 0, Gd + e->outw, pd * d, 0);
+    colsum(e->dout, M, pd, Gd + e->outb);
+    HIP_TRY(hipMemsetAsync(e->dy, 0, (size_t)B * 2 * d * 4, s));
+
+    for (int i = e->L - 1; i >= 0; --i) {
+        LayerB& b = e->lb[i]; const LayerP& p = e->lp[i];
+        // ---- MLP: o = g Wdown^T + b;  g = GELU(hc);  hc = dwconv(h);  h = a3 Wup^T + b;  a3 = LN3(x3)
+        hipLaunchKernelGGL(cast_f32_bf16, g1((size_t)M * d), blk, 0, s, e->gx, e->gxb, (size_t)M * d);
+        colsum(e->gxb, M, d, Gd + p.down_b);
+        weight_grad(e->gxb, d, b.gl, hid, Gd + p.down_w);
+        gemm_bf16(e->gxb, d, b.wdown_t, d, e->zero_bias, e->dbig, M, hid, d, s);                         // dg = go Wdown
+        hipLaunchKernelGGL(gelu_bwd_kernel, g1((size_t)M * hid), blk, 0, s, e->dbig, b.hc, e->dbig, (size_t)M * hid);      // dhc (in place)
+        hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((hid + 255) / 256, B), blk, 0, s, e->dbig, b.h, e->part, G, hid);
+        hipLaunchKernelGGL(dwconv_wgrad_reduce, g1((size_t)hid * 10), blk, 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B, hid);
+        hipLaunchKernelGGL(dwconv_kernel, g1((size_t)M * hid), blk, 0, s, e->dbig, P + p.dw_w, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1);   // dh -> b.gl (its forward value is consumed)
+        colsum(b.gl, M, hid, Gd + p.up_b);
+        weight_grad(b.gl, hid, b.a3, d, Gd + p.up_w);
+        gemm_bf16(b.gl, hid, b.wup_t, hid, e->zero_bias, e->dsmall2, M, d, hid, s);                     // da3 = dh Wup
+        ln_bwd_rows(e->dsmall2, b.x3, b.st3, P + p.n3w, e->gx, 1, Gd + p.n3w, Gd + p.n3b, M, d);
+        // ---- cross-attention: cr = CA(qc, kv);  qc = a2 Wq^T;  kv = y Wkv^T;  a2 = LN2(x2)
+        hipLaunchKernelGGL(cross_bwd_kernel, dim3(B * H), blk, (size_t)2 * N * 4, s, e->gx, b.qc, b.kvc, b.p0, e->dsmall2, e->dkv, N, d);   // dqc -> dsmall2
+        hipLaunchKernelGGL(small_linear_dw, g1((size_t)2 * d * d), blk, 0, s, e->dkv, 2 * d, e->y, d, Gd + p.kv, (float*)nullptr, 2 * B, 2 * d, d, 0);
+        hipLaunchKernelGGL(small_linear_dx, g1((size_t)2 * B * d), blk, 0, s, e->dkv, 2 * d, P + p.kv, e->dy, d, 2 * B, 2 * d, d, 1);
+        weight_grad(e->dsmall2, d, b.a2, d, Gd + p.q);
+        gemm_bf16(e->dsmall2, d, b.wq_t, d, e->zero_bias, e->dsmall, M, d, d, s);                       // da2 = dqc Wq
+        ln_bwd_rows(e->dsmall, b.x2, b.st2, P + p.n2w, e->gx, 1, Gd + p.n2w, Gd + p.n2b, M, d);
+        // ---- self-attention: att = SDPA(q, k, v);  qkv = a1 Wqkv^T;  a1 = LN1(x1)
+        if (launch_attention_bwd(b.qk, b.vt, b.att, e->gx, e->dsmall, B, N, H, s)) return tfail(TLD_ERR_INVALID, "attention backward supports 256 tokens");
+        weight_grad(e->dsmall, 3 * d, b.a1, d, Gd + p.qkv);
+        gemm_bf16(e->dsmall, 3 * d, b.wqkv_t, 3 * d, e->zero_bias, e->dsmall2, M, d, 3 * d, s);         // da1 = dqkv Wqkv
+        ln_bwd_rows(e->dsmall2, b.x1, b.st1, P + p.n1w, e->gx, 1, Gd + p.n1w, Gd + p.n1b, M, d);
+    }
+    // ---- patch embedding: x0 = LN2(e) + pos;  e = pn Wlin^T + b;  pn = LN1(p);  p = conv(x)     (tld/denoiser.py:34-45,75-77)
+    hipLaunchKernelGGL(pos_grad_kernel, g1((size_t)N * d), blk, 0, s, e->gx, Gd + e->pos, B, N, d);
+    ln_bwd_rows(e->gx, e->e, e->est2, P + e->l2w, e->de, 0, Gd + e->l2w, Gd + e->l2b, M, d);
+    colsum(e->de, M, d, Gd + e->lib);
+    hipLaunchKernelGGL(small_linear_dx, g1((size_t)M * pd), blk, 0, s, e->de, d, P + e->liw, e->dpn, pd, M, d, pd, 0);               // dpn = de Wlin
+    hipLaunchKernelGGL((tall_dw_partial<float>), dim3((pd * d + 255) / 256, nchunk), blk, 0, s, e->p16n, pd, e->de, d, M, 256, e->part);
+    reduce(nchunk, (size_t)pd * d, 0, e->scr, pd * d, 0);                                                                              // dWlin^T [pd, d]
+    hipLaunchKernelGGL(transpose_f32_small, g1((size_t)pd * d), blk, 0, s, e->scr, Gd + e->liw, pd, d);
+    hipLaunchKernelGGL(ln_small_bwd_kernel, dim3(nchunk), blk, 0, s, e->dpn, e->p16, e->est1, P + e->l1w, e->dp16, e->part, M, pd);
+    reduce(nchunk, 2 * (size_t)pd, 0, Gd + e->l1w, pd, 0);
+    reduce(nchunk, 2 * (size_t)pd, pd, Gd + e->l1b, pd, 0);
+    hipLaunchKernelGGL(patches_kernel, g1((size_t)M * pd), blk, 0, s, x_noisy, e->patches, B, e->C, e->S, e->cfg.patch_size, G);
+    hipLaunchKernelGGL((tall_dw_partial<float>), dim3((pd * pd + 255) / 256, nchunk), blk, 0, s, e->dp16, pd, e->patches, pd, M, 256, e->part);
+    reduce(nchunk, (size_t)pd * pd, 0, Gd + e->cvw, pd * pd, 0);
+    colsum(e->dp16, M, pd, Gd + e->cvb);
+    // ---- conditioning: y = LN(stack[nz, lb]);  nz = W3 GELU(W1 sin + b1) + b3;  lb = label_proj(label)     (tld/denoiser.py:105-122)
+    ln_bwd_rows(e->dy, e->ycat, e->yst, P + e->nw, e->dycat, 0, Gd + e->nw, Gd + e->nb, 2 * B, d);
+    hipLaunchKernelGGL(small_linear_dw, g1((size_t)d * e->text), blk, 0, s, e->dycat + d, 2 * d, label, e->text, Gd + e->lbw, Gd + e->lbb, B, d, e->text, 0);
+    hipLaunchKernelGGL(small_linear_dw, g1((size_t)d * d), blk, 0, s, e->dycat, 2 * d, e->g1v, d, Gd + e->ff3w, Gd + e->ff3b, B, d, d, 0);
+    hipLaunchKernelGGL(small_linear_dx, g1((size_t)B * d), blk, 0, s, e->dycat, 2 * d, P + e->ff3w, e->dg1, d, B, d, d, 0);
+    hipLaunchKernelGGL(mul_gelu_grad, g1((size_t)B * d), blk, 0, s, e->dg1, e->h1, B * d);
+    hipLaunchKernelGGL(small_linear_dw, g1((size_t)d * e->ne), blk, 0, s, e->dg1, d, e->sinb, e->ne, Gd + e->ff1w, Gd + e->ff1b, B, d, e->ne, 0);
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
+/* optimizer.step() of torch.optim.Adam(model.parameters(), lr) (tld/train.py:87,169) fused with update_ema (tld/train.py:55-58,172) over
+ * flat fp32 device vectors; step counts from 1.  ema may be NULL (ranks other than the main process hold no EMA copy, :110-112).
+ * grad_scale multiplies the gradient first (1 / world_size after a SUM all-reduce). */
+int tld_train_adam_ema(tld_train* e, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel, float lr,
+                       float beta1, float beta2, float eps, int32_t step, float ema_alpha, float grad_scale, void* hip_stream) {
+    if (!params || !grads || !exp_avg || !exp_avg_sq || numel <= 0 || step <= 0) return tfail(TLD_ERR_INVALID, "bad argument");
+    DevGuard dg(e ? e->cfg.device_id : 0);
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_ema_kernel, g1((size_t)numel), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, ema, (size_t)numel, lr, beta1, beta2, eps, bc1, bc2,
+                       ema_alpha, grad_scale);
+    HIP_TRY(hipGetLastError());
+    if (e && params == e->params) e->weights_fresh = false;          // the bf16 operand copies are stale now
+    return TLD_OK;
+}
+
+/* Test hook: backward of softmax(Q K^T / 8) V for `batch` samples x `heads` heads over 256 tokens.  qk [M, 2 d] bf16 (q | k), vt [B, H, 64, 256]
+ * bf16, o [M, d] bf16 (the forward output), g [M, d] fp32 (dL/dO); dqkv [M, 3 d] bf16 out (dq | dk | dv).  Device pointers. */
+int tld_debug_attention_bwd(const void* qk, const void* vt, const void* o, const float* g, void* dqkv, int32_t batch, int32_t heads, void* hip_stream) {
+    if (!qk || !vt || !o || !g || !dqkv || batch <= 0 || heads <= 0) return tfail(TLD_ERR_INVALID, "bad argument");
+    if (launch_attention_bwd(reinterpret_cast<const bf16*>(qk), reinterpret_cast<const bf16*>(vt), reinterpret_cast<const bf16*>(o), g,
+                             reinterpret_cast<bf16*>(dqkv), batch, 256, heads, reinterpret_cast<hipStream_t>(hip_stream)))
+        return tfail(TLD_ERR_INVALID, "attention backward supports 256 tokens");
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
+int tld_train_destroy(tld_train* e) {
+    if (!e) return TLD_OK;
+    DevGuard dg(e->cfg.device_id);
+    for (void* p : e->allocs) hipFree(p);
+    delete e;
+    return TLD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,567 @@
+// tld_train_kernels.h -- device kernels of the training step (tld/train.py:118-175): the row / elementwise /
+// reduction pieces of the forward-with-saved-activations and of the backward pass.  The dense contractions (projections and their
+// dX / dW products) run on the MFMA GEMM of tld_gemm.hip; self-attention backward is tld_train_attn.hip.  Included by tld_train.hip only.
+//
+// Conventions: a wave owns a token row where a row reduction is needed (lane l holds features l + 64 j); fp32 arithmetic throughout,
+// bf16 only as the storage type of the large saved activations.  Parameter-gradient reductions over the batch are two-stage
+// (fixed-size partials, then a sum in a fixed order), so a step is bit-reproducible.
+#pragma once
+#include "tld_common.h"
+
+namespace tld {
+namespace train {
+
+constexpr int kMaxJ = 16;          // features per lane: d <= 1024
+constexpr float kEps = 1e-5f;
+
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16* p) { return (float)*p; }
+
+// exact-erf GELU and its derivative (nn.GELU default; tld/denoiser.py:108, tld/transformer_blocks.py:103)
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// ---- small fp32 linears (conditioning path, out-projection pieces: R rows <= a few hundred or N, K small) --------------------------
+// out[r, n] = act(b[n] + sum_k in[r, k] W[n, k])
+__global__ void small_linear_fwd(const float* __restrict__ in, int ldi, const float* __restrict__ W, const float* __restrict__ b,
+                                 float* __restrict__ out, int ldo, int R, int N, int K, float* __restrict__ pre /*nullable: pre-activation*/, int gelu) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * N) return;
+    const int r = idx / N, n = idx - r * N;
+    float a = b ? b[n] : 0.f;
+    const float* x = in + (size_t)r * ldi;
+    const float* w = W + (size_t)n * K;
+    for (int k = 0; k < K; ++k) a = fmaf(x[k], w[k], a);
+    if (pre) pre[(size_t)r * ldo + n] = a;
+    out[(size_t)r * ldo + n] = gelu ? gelu_exact(a) : a;
+}
+// dx[r, k] (+)= sum_n dy[r, n] W[n, k]
+__global__ void small_linear_dx(const float* __restrict__ dy, int ldy, const float* __restrict__ W, float* __restrict__ dx, int ldx,
+                                int R, int N, int K, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R * K) return;
+    const int r = idx / K, k = idx - r * K;
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a = fmaf(dy[(size_t)r * ldy + n], W[(size_t)n * K + k], a);
+    float* o = dx + (size_t)r * ldx + k;
+    *o = accumulate ? *o + a : a;
+}
+// dW[n, k] (+)= sum_r dy[r, n] x[r, k];  db[n] (+)= sum_r dy[r, n]
+__global__ void small_linear_dw(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx, float* __restrict__ dW,
+                                float* __restrict__ db, int R, int N, int K, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * K) return;
+    const int n = idx / K, k = idx - n * K;
+    float a = 0.f, s = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float g = dy[(size_t)r * ldy + n];
+        a = fmaf(g, x[(size_t)r * ldx + k], a);
+        s += g;
+    }
+    dW[idx] = accumulate ? dW[idx] + a : a;
+    if (db && k == 0) db[n] = accumulate ? db[n] + s : s;
+}
+__global__ void mul_gelu_grad(float* __restrict__ g, const float* __restrict__ pre, int n) {     // g *= GELU'(pre)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) g[i] *= gelu_grad(pre[i]);
+}
+
+// ---- LayerNorm (eps 1e-5, biased variance, affine; tld/transformer_blocks.py:131-133, tld/denoiser.py:42,44,113) -----------------
+// forward: one wave per row;  out = (x - mean) rstd gamma + beta  [+ add[row % add_rows]]  as bf16 and / or fp32;  stats = (mean, rstd)
+template <typename TX>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     bf16* __restrict__ out_bf, float* __restrict__ out_f, float2* __restrict__ stats,
+                                                     const float* __restrict__ add, int add_rows, int M, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int J = d >> 6;
+    float v[kMaxJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) { v[j] = ldf(x + (size_t)row * d + lane + 64 * j); s += v[j]; }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) { const float c = v[j] - mean; q = fmaf(c, c, q); }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + kEps);
+    if (lane == 0 && stats) stats[row] = make_float2(mean, rstd);
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) {
+        const int c = lane + 64 * j;
+        float o = (v[j] - mean) * rstd * gamma[c] + beta[c];
+        if (add) o += add[(size_t)(row % add_rows) * d + c];
+        if (out_bf) out_bf[(size_t)row * d + c] = (bf16)o;
+        if (out_f) out_f[(size_t)row * d + c] = o;
+    }
+}
+// backward: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;  written (accumulate = 0) or added (1) into dx (fp32);
+// per-workgroup partial sums of dgamma = sum dy xhat and dbeta = sum dy over the workgroup's rows -> part[blockIdx][2][d]
+template <typename TDY, typename TX>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float2* __restrict__ stats,
+                                                     const float* __restrict__ gamma, float* __restrict__ dx, int accumulate,
+                                                     float* __restrict__ part, int rows_per_block, int M, int d) {
+    __shared__ float red[4][2][1024];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int J = d >> 6;
+    float dg[kMaxJ], db[kMaxJ];
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+    const int r0 = blockIdx.x * rows_per_block;
+    for (int rr = wid; rr < rows_per_block; rr += 4) {
+        const int row = r0 + rr;
+        if (row >= M) break;
+        const float2 st = stats[row];
+        float g[kMaxJ], xh[kMaxJ];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxJ; ++j) if (j < J) {
+            const int c = lane + 64 * j;
+            const float dyv = ldf(dy + (size_t)row * d + c);
+            xh[j] = (ldf(x + (size_t)row * d + c) - st.x) * st.y;
+            g[j] = dyv * gamma[c];
+            s1 += g[j]; s2 = fmaf(g[j], xh[j], s2);
+            dg[j] = fmaf(dyv, xh[j], dg[j]); db[j] += dyv;
+        }
+        const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int j = 0; j < kMaxJ; ++j) if (j < J) {
+            const float o = st.y * (g[j] - m1 - xh[j] * m2);
+            float* px = dx + (size_t)row * d + lane + 64 * j;
+            *px = accumulate ? *px + o : o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) { red[wid][0][lane + 64 * j] = dg[j]; red[wid][1][lane + 64 * j] = db[j]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        part[((size_t)blockIdx.x * 2 + 0) * d + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
+        part[((size_t)blockIdx.x * 2 + 1) * d + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+    }
+}
+// out[c] (+)= sum_i part[i * stride + c]   (fixed order: bit-reproducible)
+__global__ void reduce_partials(const float* __restrict__ part, int nparts, size_t stride, float* __restrict__ out, int n, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float a = 0.f;
+    for (int i = 0; i < nparts; ++i) a += part[(size_t)i * stride + c];
+    out[c] = accumulate ? out[c] + a : a;
+}
+// column sums of a [M, C] matrix over row chunks: part[chunk][C]
+template <typename T>
+__global__ void colsum_partial(const T* __restrict__ a, int M, int C, int rows_per_chunk, float* __restrict__ part) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += ldf(a + (size_t)r * C + c);
+    part[(size_t)blockIdx.y * C + c] = s;
+}
+
+// LayerNorm backward over NARROW rows (width <= 64: the patch LayerNorm, tld/denoiser.py:42): one thread per row;
+// dgamma / dbeta partials per 256-row workgroup -> part[blockIdx][2][width]
+__global__ __launch_bounds__(256) void ln_small_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float2* __restrict__ stats,
+                                                           const float* __restrict__ gamma, float* __restrict__ dx, float* __restrict__ part, int M, int width) {
+    __shared__ float red[256][33];
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    // pass over the columns in groups of 16 so that the shared tile stays small: (dy xhat, dy) pairs of 16 columns
+    float xh[64], g[64];
+    float m1 = 0.f, m2 = 0.f;
+    float2 st = make_float2(0.f, 0.f);
+    if (row < M) {
+        st = stats[row];
+        for (int c = 0; c < width; ++c) {
+            xh[c] = (x[(size_t)row * width + c] - st.x) * st.y;
+            g[c] = dy[(size_t)row * width + c] * gamma[c];
+            m1 += g[c]; m2 = fmaf(g[c], xh[c], m2);
+        }
+        m1 /= (float)width; m2 /= (float)width;
+        for (int c = 0; c < width; ++c) dx[(size_t)row * width + c] = st.y * (g[c] - m1 - xh[c] * m2);
+    }
+    for (int c0 = 0; c0 < width; c0 += 16) {
+        const int nc = min(16, width - c0);
+        for (int c = 0; c < nc; ++c) {
+            const float dyv = row < M ? dy[(size_t)row * width + c0 + c] : 0.f;
+            red[threadIdx.x][c] = row < M ? dyv * xh[c0 + c] : 0.f;
+            red[threadIdx.x][16 + c] = dyv;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * nc) {
+            const int which = threadIdx.x / nc, c = threadIdx.x % nc;
+            float a = 0.f;
+            for (int r = 0; r < 256; ++r) a += red[r][which * 16 + c];
+            part[((size_t)blockIdx.x * 2 + which) * width + c0 + c] = a;
+        }
+        __syncthreads();
+    }
+}
+__global__ void transpose_f32_small(const float* __restrict__ in /*[R, C]*/, float* __restrict__ out /*[C, R]*/, int R, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * C) return;
+    const int r = i / C, c = i - r * C;
+    out[(size_t)c * R + r] = in[i];
+}
+
+// ---- residual stream --------------------------------------------------------------------------------------------------------
+// x_out = bf16(x_in + delta)  (the stored stream, as at inference);  optionally the next LayerNorm of the STORED row in the same pass
+__global__ __launch_bounds__(256) void resid_add_ln_kernel(const bf16* __restrict__ x_in, const bf16* __restrict__ delta, bf16* __restrict__ x_out,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ a_out,
+                                                           float2* __restrict__ stats, int M, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int J = d >> 6;
+    float v[kMaxJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) {
+        const size_t o = (size_t)row * d + lane + 64 * j;
+        const bf16 r = (bf16)((float)x_in[o] + (float)delta[o]);
+        x_out[o] = r;
+        v[j] = (float)r; s += v[j];
+    }
+    if (!a_out) return;
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) { const float c = v[j] - mean; q = fmaf(c, c, q); }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + kEps);
+    if (lane == 0) stats[row] = make_float2(mean, rstd);
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) {
+        const int c = lane + 64 * j;
+        a_out[(size_t)row * d + c] = (bf16)((v[j] - mean) * rstd * gamma[c] + beta[c]);
+    }
+}
+
+// ---- layout helpers -----------------------------------------------------------------------------------------------------------
+// [R, C] -> [C, R] (bf16 out), 32 x 32 tiles through LDS;  TIN = bf16 or float (rounded once)
+template <typename TIN>
+__global__ __launch_bounds__(256) void transpose_to_bf16(const TIN* __restrict__ in, int ldi, bf16* __restrict__ out, int ldo, int R, int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? ldf(in + (size_t)r * ldi + c) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) out[(size_t)c * ldo + r] = (bf16)tile[tx][i];
+    }
+}
+__global__ void cast_f32_bf16(const float* __restrict__ in, bf16* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bf16)in[i];
+}
+// V^T [B, H, 64, N] (the attention kernel's operand) -> v row-major [B N, d]
+__global__ void vt_to_rows(const bf16* __restrict__ vt, bf16* __restrict__ v, int B, int H, int N) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // over B * N * d, feature fastest
+    const int d = H * 64;
+    if (i >= (size_t)B * N * d) return;
+    const int f = (int)(i % d);
+    const size_t m = i / d;
+    const int b = (int)(m / N), t = (int)(m % N);
+    v[i] = vt[(((size_t)b * H + (f >> 6)) * 64 + (f & 63)) * N + t];
+}
+
+// ---- patch embedding (tld/denoiser.py:34-45,75-77) ------------------------------------------------------------------------------
+// forward, one wave per token: conv(k = s = patch) -> p [pd] -> LN(pd) -> Linear(pd, d) -> e [d] -> LN(d) -> + pos -> x0 (bf16)
+struct EmbedTrain {
+    const float* x;            // [B, C, S, S] fp32
+    const float *conv_w, *conv_b, *ln1_w, *ln1_b, *lin_w /*[d, pd]*/, *lin_b, *ln2_w, *ln2_b, *pos /*[N, d]*/;
+    float* p;                  // [M, pd]  conv output
+    float* pn;                 // [M, pd]  after LN(pd)
+    float2* st1;               // [M]
+    float* e;                  // [M, d]   Linear output
+    float2* st2;               // [M]
+    bf16* x0;                  // [M, d]
+    int B, C, S, patch, grid, pd, d;
+};
+__global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedTrain q) {
+    const int N = q.grid * q.grid, M = q.B * N;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int b = row / N, t = row - b * N, gy = t / q.grid, gx = t - gy * q.grid;
+    const int pp = q.patch * q.patch, taps = q.C * pp;
+    // lane f < pd: feature f of the patch convolution
+    float pv = 0.f;
+    if (lane < q.pd) {
+        pv = q.conv_b[lane];
+        for (int k = 0; k < taps; ++k) {
+            const int c = k / pp, r = k - c * pp, p1 = r / q.patch, p2 = r - p1 * q.patch;
+            pv = fmaf(q.conv_w[lane * taps + k], q.x[(((size_t)b * q.C + c) * q.S + gy * q.patch + p1) * q.S + gx * q.patch + p2], pv);
+        }
+        q.p[(size_t)row * q.pd + lane] = pv;
+    }
+    const float m1 = wave_sum(lane < q.pd ? pv : 0.f) / (float)q.pd;
+    const float c1 = lane < q.pd ? pv - m1 : 0.f;
+    const float r1 = rsqrtf(wave_sum(c1 * c1) / (float)q.pd + kEps);
+    const float pn = lane < q.pd ? c1 * r1 * q.ln1_w[lane] + q.ln1_b[lane] : 0.f;
+    if (lane < q.pd) q.pn[(size_t)row * q.pd + lane] = pn;
+    if (lane == 0) q.st1[row] = make_float2(m1, r1);
+    const int J = q.d >> 6;
+    float ev[kMaxJ];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) {
+        const int c = lane + 64 * j;
+        float a = q.lin_b[c];
+        for (int f = 0; f < q.pd; ++f) a = fmaf(__shfl(pn, f, 64), q.lin_w[c * q.pd + f], a);
+        ev[j] = a; s += a;
+        q.e[(size_t)row * q.d + c] = a;
+    }
+    const float m2 = wave_sum(s) / (float)q.d;
+    float v2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) { const float c = ev[j] - m2; v2 = fmaf(c, c, v2); }
+    const float r2 = rsqrtf(wave_sum(v2) / (float)q.d + kEps);
+    if (lane == 0) q.st2[row] = make_float2(m2, r2);
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) {
+        const int c = lane + 64 * j;
+        q.x0[(size_t)row * q.d + c] = (bf16)((ev[j] - m2) * r2 * q.ln2_w[c] + q.ln2_b[c] + q.pos[(size_t)t * q.d + c]);
+    }
+}
+// dpos[t, c] = sum_b g[b N + t, c]
+__global__ void pos_grad_kernel(const float* __restrict__ g, float* __restrict__ dpos, int B, int N, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * d) return;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += g[(size_t)b * N * d + i];
+    dpos[i] = a;
+}
+// gather the patch pixels of every token as a matrix [M, C p p] (operand of the conv-weight gradient)
+__global__ void patches_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int C, int S, int patch, int grid) {
+    const int pp = patch * patch, taps = C * pp, N = grid * grid;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * N * taps) return;
+    const int k = (int)(i % taps);
+    const size_t m = i / taps;
+    const int b = (int)(m / N), t = (int)(m % N), gy = t / grid, gx = t - gy * grid;
+    const int c = k / pp, r = k - c * pp, p1 = r / patch, p2 = r - p1 * patch;
+    out[i] = x[(((size_t)b * C + c) * S + gy * patch + p1) * S + gx * patch + p2];
+}
+
+// ---- cross-attention over the two conditioning tokens (tld/transformer_blocks.py:62-72) -----------------------------------------------
+// One workgroup per (sample, head), one thread per token.  kv [B, 2, 2d] fp32 = (k | v) of tokens (noise, label).
+// forward:  p0 = softmax([q.k0, q.k1] / 8)[0];  out = p0 v0 + (1 - p0) v1
+__global__ void cross_fwd_kernel(const bf16* __restrict__ q, const float* __restrict__ kv, bf16* __restrict__ out, float* __restrict__ p0_out,
+                                 int N, int d) {
+    const int H = d >> 6, b = blockIdx.x / H, h = blockIdx.x % H;
+    __shared__ float sk[2][64], sv[2][64];
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x >> 6, i = threadIdx.x & 63;
+        sk[t][i] = kv[((size_t)b * 2 + t) * 2 * d + h * 64 + i];
+        sv[t][i] = kv[((size_t)b * 2 + t) * 2 * d + d + h * 64 + i];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < N; t += blockDim.x) {
+        const size_t row = (size_t)b * N + t;
+        const bf16* qr = q + row * d + h * 64;
+        float s0 = 0.f, s1 = 0.f;
+        for (int i = 0; i < 64; ++i) { const float qi = (float)qr[i]; s0 = fmaf(qi, sk[0][i], s0); s1 = fmaf(qi, sk[1][i], s1); }
+        const float p0 = 1.0f / (1.0f + __expf((s1 - s0) * 0.125f));
+        p0_out[row * H + h] = p0;
+        bf16* o = out + row * d + h * 64;
+        for (int i = 0; i < 64; ++i) o[i] = (bf16)(p0 * sv[0][i] + (1.0f - p0) * sv[1][i]);
+    }
+}
+// backward:  g = dL/dout (fp32 [M, d]).  dq -> bf16 [M, d];  dkv[b, t, :] (fp32, written: one workgroup owns a (sample, head) slice)
+__global__ void cross_bwd_kernel(const float* __restrict__ g, const bf16* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ p0_in,
+                                 bf16* __restrict__ dq, float* __restrict__ dkv, int N, int d) {
+    const int H = d >> 6, b = blockIdx.x / H, h = blockIdx.x % H;
+    __shared__ float sk[2][64], sv[2][64];
+    extern __shared__ float sm[];                 // [N] ds0, [N] p0
+    float* ds = sm; float* pp = sm + N;
+    if (threadIdx.x < 128) {
+        const int t = threadIdx.x >> 6, i = threadIdx.x & 63;
+        sk[t][i] = kv[((size_t)b * 2 + t) * 2 * d + h * 64 + i];
+        sv[t][i] = kv[((size_t)b * 2 + t) * 2 * d + d + h * 64 + i];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < N; t += blockDim.x) {
+        const size_t row = (size_t)b * N + t;
+        const float* gr = g + row * d + h * 64;
+        float d0 = 0.f, d1 = 0.f;
+        for (int i = 0; i < 64; ++i) { d0 = fmaf(gr[i], sv[0][i], d0); d1 = fmaf(gr[i], sv[1][i], d1); }
+        const float p0 = p0_in[row * H + h];
+        const float s0 = p0 * (1.0f - p0) * (d0 - d1);                     // dL/ds0 = -dL/ds1  (scores before the 1/8 scale: x 1/8 below)
+        ds[t] = s0 * 0.125f; pp[t] = p0;
+        bf16* o = dq + row * d + h * 64;
+        for (int i = 0; i < 64; ++i) o[i] = (bf16)(s0 * 0.125f * (sk[0][i] - sk[1][i]));
+    }
+    __syncthreads();
+    // reductions over the sample's tokens: thread i < 64 owns feature i of this head
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        float dk0 = 0.f, dv0 = 0.f, dv1 = 0.f;
+        for (int t = 0; t < N; ++t) {
+            const size_t row = (size_t)b * N + t;
+            const float gi = g[row * d + h * 64 + i];
+            dk0 = fmaf(ds[t], (float)q[row * d + h * 64 + i], dk0);
+            dv0 = fmaf(pp[t], gi, dv0);
+            dv1 = fmaf(1.0f - pp[t], gi, dv1);
+        }
+        float* o0 = dkv + ((size_t)b * 2 + 0) * 2 * d;
+        float* o1 = dkv + ((size_t)b * 2 + 1) * 2 * d;
+        o0[h * 64 + i] = dk0; o1[h * 64 + i] = -dk0;
+        o0[d + h * 64 + i] = dv0; o1[d + h * 64 + i] = dv1;
+    }
+}
+
+// ---- depthwise 3x3 (zero "same" padding, cross-correlation) + GELU (tld/transformer_blocks.py:96-103) --------------------------------
+// channels-last image [B, G, G, C] == token-major [M, C].  w [C, 3, 3] fp32 (the reference's [C, 1, 3, 3]).
+// forward (flip = 0): out = b + sum_taps w[c][ky][kx] in[y + ky - 1][x + kx - 1];  also gelu_out = GELU(out) when given.
+// input gradient (flip = 1, no bias): din[y][x] = sum_taps w[c][ky][kx] dout[y - ky + 1][x - kx + 1]
+__global__ void dwconv_kernel(const bf16* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, bf16* __restrict__ out,
+                              bf16* __restrict__ gelu_out, int B, int G, int C, int flip) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * G * G * C) return;
+    const int c = (int)(i % C);
+    const size_t m = i / C;
+    const int x = (int)(m % G), y = (int)((m / G) % G);
+    const size_t b = m / ((size_t)G * G);
+    float a = (bias && !flip) ? bias[c] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = flip ? y - ky + 1 : y + ky - 1, xx = flip ? x - kx + 1 : x + kx - 1;
+            if ((unsigned)yy < (unsigned)G && (unsigned)xx < (unsigned)G)
+                a = fmaf(w[c * 9 + ky * 3 + kx], (float)in[((b * G + yy) * G + xx) * C + c], a);
+        }
+    out[i] = (bf16)a;
+    if (gelu_out) gelu_out[i] = (bf16)gelu_exact((float)(bf16)a);        // GELU of the STORED pre-activation: what the backward differentiates
+}
+// dhc = dg * GELU'(hc)
+__global__ void gelu_bwd_kernel(const bf16* __restrict__ dg, const bf16* __restrict__ hc, bf16* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bf16)((float)dg[i] * gelu_grad((float)hc[i]));
+}
+// weight / bias gradient partials per sample: part[b][10][C]: taps 0..8, then the bias;  thread per channel
+__global__ void dwconv_wgrad_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ in, float* __restrict__ part, int G, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const size_t b = blockIdx.y;
+    float acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    for (int y = 0; y < G; ++y)
+        for (int x = 0; x < G; ++x) {
+            const float gv = (float)dout[((b * G + y) * G + x) * C + c];
+            acc[9] += gv;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int yy = y + ky - 1, xx = x + kx - 1;
+                    if ((unsigned)yy < (unsigned)G && (unsigned)xx < (unsigned)G)
+                        acc[ky * 3 + kx] = fmaf(gv, (float)in[((b * G + yy) * G + xx) * C + c], acc[ky * 3 + kx]);
+                }
+        }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) part[(b * 10 + k) * C + c] = acc[k];
+}
+// dw [C, 9] / db [C] from part[B][10][C]
+__global__ void dwconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int B, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 10) return;
+    const int c = i % C, k = i / C;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += part[((size_t)b * 10 + k) * C + c];
+    if (k < 9) dw[c * 9 + k] = a; else db[c] = a;
+}
+
+// ---- output projection + unpatchify + loss (tld/denoiser.py:47-52,72,82; tld/train.py:167) -----------------------------------------------
+// forward, one wave per token: o[f] = b[f] + x . W[f];  pred[b, c, gy p + p1, gx p + p2] = o[c p p + p1 p + p2];  sq-error partial per row
+__global__ __launch_bounds__(256) void tail_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                                       const float* __restrict__ target, float* __restrict__ pred, float* __restrict__ dout /*[M, pd]*/,
+                                                       float* __restrict__ row_loss, int B, int C, int S, int patch, int grid, int pd, int d, float inv_numel) {
+    const int N = grid * grid, M = B * N;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int b = row / N, t = row - b * N, gy = t / grid, gx = t - gy * grid;
+    const int J = d >> 6, pp = patch * patch;
+    float xv[kMaxJ];
+#pragma unroll
+    for (int j = 0; j < kMaxJ; ++j) if (j < J) xv[j] = (float)x[(size_t)row * d + lane + 64 * j];
+    float sq = 0.f;
+    for (int f = 0; f < pd; ++f) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxJ; ++j) if (j < J) a = fmaf(xv[j], W[(size_t)f * d + lane + 64 * j], a);
+        a = wave_sum(a) + bias[f];
+        const int c = f / pp, r = f - c * pp, p1 = r / patch, p2 = r - p1 * patch;
+        const size_t pi = (((size_t)b * C + c) * S + gy * patch + p1) * S + gx * patch + p2;
+        const float diff = a - target[pi];
+        if (lane == 0) {
+            pred[pi] = a;
+            dout[(size_t)row * pd + f] = 2.0f * diff * inv_numel;             // d mean((pred - target)^2) / d pred
+        }
+        sq = fmaf(diff, diff, sq);
+    }
+    if (lane == 0) row_loss[row] = sq;
+}
+// loss = inv_numel * sum_rows row_loss  (one workgroup, fixed order)
+__global__ void loss_reduce_kernel(const float* __restrict__ row_loss, int M, float inv_numel, float* __restrict__ loss) {
+    __shared__ float red[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < M; i += 256) a += row_loss[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) *loss = red[0] * inv_numel;
+}
+// backward into the stream: gx[row, c] = sum_f dout[row, f] W[f, c]   (fp32, written)
+__global__ void tail_dx_kernel(const float* __restrict__ dout, const float* __restrict__ W, float* __restrict__ gx, int M, int pd, int d) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * d) return;
+    const int c = (int)(i % d);
+    const size_t row = i / d;
+    float a = 0.f;
+    for (int f = 0; f < pd; ++f) a = fmaf(dout[row * pd + f], W[(size_t)f * d + c], a);
+    gx[i] = a;
+}
+// generic "tall" weight gradient with a SMALL output (out-projection, patch Linear, patch conv):
+// part[chunk][n][k] = sum_{rows of chunk} dy[r, n] x[r, k];  n < Nn <= 64, thread per (n, k);  dy fp32, x bf16 or fp32
+template <typename TX>
+__global__ void tall_dw_partial(const float* __restrict__ dy, int Nn, const TX* __restrict__ x, int K, int M, int rows_per_chunk, float* __restrict__ part) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nn * K) return;
+    const int n = i / K, k = i - n * K;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float a = 0.f;
+    for (int r = r0; r < r1; ++r) a = fmaf(dy[(size_t)r * Nn + n], ldf(x + (size_t)r * K + k), a);
+    part[(size_t)blockIdx.y * Nn * K + i] = a;
+}
+
+// ---- sinusoidal embedding (tld/transformer_blocks.py:7-21) -------------------------------------------------------------------------
+__global__ void sinusoid_kernel(const float* __restrict__ sigma, const float* __restrict__ angular, float* __restrict__ out, int B, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, k = i - b * half;
+    const float a = sigma[b] * angular[k];
+    out[(size_t)b * 2 * half + k] = sinf(a);
+    out[(size_t)b * 2 * half + half + k] = cosf(a);
+}
+
+// ---- optimizer: Adam (torch.optim.Adam defaults: no weight decay, no amsgrad) + EMA (tld/train.py:55-58,169) --------------------------
+// grad_scale multiplies the gradient first (1 / world_size after a sum all-reduce).  bias corrections passed as 1 - beta^t.
+__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, float* __restrict__ ema,
+                                size_t n, float lr, float b1, float b2, float eps, float bc1, float bc2, float alpha, float grad_scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;            // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;       // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    const float pi = p[i] - (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    if (ema) ema[i] = ema[i] * alpha + pi * (1.0f - alpha);   // ema.mul_(alpha).add_(param, alpha = 1 - alpha)
+}
+
+}  // namespace train
+}  // namespace tld

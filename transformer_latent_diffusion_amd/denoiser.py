@@ -65,7 +65,7 @@ class Denoiser:
 
     def train(self, mode: bool = True) -> "Denoiser":
         if mode:
-            raise NotImplementedError("this engine implements the inference path only (no training step)")
+            raise NotImplementedError("this object is the inference engine; the training step (tld/train.py:118-175) is transformer_latent_diffusion_amd.Trainer")
         return self.eval()
 
     def to(self, *args, **kwargs) -> "Denoiser":

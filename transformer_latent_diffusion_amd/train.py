@@ -1,0 +1,249 @@
+"""Training step of the denoiser on the gfx950 engine -- the host side of ``tld_train_*``.
+
+Mirrors the body of the reference's training loop (tld/train.py:118-175) for one batch:
+
+    noise_level ~ Beta(beta_a, beta_b);  x_noisy = noise_level * noise + (1 - noise_level) * x       (:120-130)  -> make_batch / mix_noise
+    label[rand < 0.15] = 0                                                                           (:135-138)  -> make_batch / drop_labels
+    pred = model(x_noisy, noise_level.view(-1, 1), label); loss = MSELoss(pred, x); backward         (:160-168)  -> Trainer.forward_backward
+    gradient all-reduce of accelerate's DDP wrapper                                                  (:114,168)  -> Trainer.optimizer_step (RCCL)
+    optimizer.step()  (Adam, lr) ; update_ema(ema_model, model, alpha)                               (:87,169-172,55-58) -> Trainer.optimizer_step
+
+Parameters, gradients, Adam moments and the EMA copy are flat fp32 torch tensors on the device (PyTorch owns the memory and the
+collective; the arithmetic is in libtld_hip.so).  There is no CPU path: constructing a ``Trainer`` without a HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from dataclasses import asdict, dataclass
+from typing import Dict, Mapping, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from .configs import DenoiserConfig
+from .weights import state_dict_spec, synth_state_dict
+
+LABEL_DROPOUT = 0.15                 # tld/train.py:135
+
+
+@dataclass
+class TrainConfig:
+    """tld/configs.py:58-72 (the fields the step itself reads: lr, alpha, beta_a, beta_b, batch_size)."""
+    batch_size: int = 128
+    lr: float = 3e-4
+    n_epoch: int = 100
+    alpha: float = 0.999
+    from_scratch: bool = True
+    beta_a: float = 1
+    beta_b: float = 2.5
+    save_and_eval_every_iters: int = 1000
+    run_id: str = ""
+    model_name: str = ""
+    compile: bool = True
+    save_model: bool = True
+    use_wandb: bool = True
+
+
+def param_layout(cfg) -> "OrderedDict[str, Tuple[int, Tuple[int, ...]]]":
+    """{key: (offset, shape)} of the flat parameter vector: ``Denoiser.named_parameters()`` order = the state_dict order without the two
+    registered buffers (``angular_speeds``, ``precomputed_pos_enc``).  The engine reports the same table (``tld_train_param_layout``)."""
+    out: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
+    off = 0
+    for k, (shape, kind) in state_dict_spec(cfg).items():
+        if kind in ("angular", "arange"):
+            continue
+        out[k] = (off, tuple(shape))
+        off += int(np.prod(shape))
+    return out
+
+
+def mix_noise(x: torch.Tensor, noise_level: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """tld/train.py:123-130: ``noise_level`` is float64 there (np.random.beta), so the mix is formed in float64 and cast to float32."""
+    nl = noise_level.to(torch.float64).view(-1, 1, 1, 1)
+    return (nl * noise + (1 - nl) * x).float()
+
+
+def drop_labels(y: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """tld/train.py:135-138 (on a copy: the reference mutates the batch tensor the loader yields)."""
+    out = y.clone()
+    out[mask] = 0
+    return out
+
+
+def allreduce_mean_(flat: torch.Tensor, group=None) -> float:
+    """DDP's gradient averaging as one collective on the flat vector: SUM all-reduce in place; returns the factor (1 / world size)
+    the optimizer kernel applies (tld/train.py:114,168: accelerate's DDP wrapper).  No-op without an initialised process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return 1.0 / dist.get_world_size(group)
+    return 1.0
+
+
+def update_ema_(ema: torch.Tensor, params: torch.Tensor, alpha: float = 0.999) -> None:
+    """tld/train.py:55-58 on flat vectors (host-side statement of what the fused kernel does; used by tests)."""
+    ema.mul_(alpha).add_(params, alpha=1 - alpha)
+
+
+class Trainer:
+    """One model replica + optimizer state on one device.  With ``torch.distributed`` initialised (backend ``nccl`` = RCCL) every rank
+    holds a replica, gradients are summed with one all-reduce of the flat vector per step and divided by the world size."""
+
+    def __init__(self, denoiser_cfg: DenoiserConfig, train_cfg: Optional[TrainConfig] = None, device="cuda",
+                 state_dict: Optional[Mapping[str, torch.Tensor]] = None, init_seed: int = 0, max_batch: Optional[int] = None,
+                 betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, keep_ema: bool = True, process_group=None):
+        self.cfg = denoiser_cfg
+        self.tc = train_cfg if train_cfg is not None else TrainConfig()
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("Trainer needs a HIP device ('cuda'); the training engine has no CPU path")
+        self.betas, self.eps = betas, eps
+        self.group = process_group
+        self.layout = param_layout(denoiser_cfg)
+        self.numel = sum(int(np.prod(s)) for _, s in self.layout.values())
+        c = asdict(denoiser_cfg)
+        L = _lib.lib()
+        self.max_batch = int(max_batch if max_batch is not None else self.tc.batch_size)
+        cc = _lib.TldConfig(c["image_size"], c["noise_embed_dims"], c["patch_size"], c["embed_dim"], c["n_layers"], c["text_emb_size"],
+                            c["n_channels"], c["mlp_multiplier"], self.max_batch, self.device.index or 0)
+        h = C.c_void_p()
+        _lib.check(L.tld_train_create(C.byref(cc), C.byref(h)), "tld_train_create")
+        self._h = h
+        try:
+            self._check_layout()
+            z = lambda: torch.zeros(self.numel, dtype=torch.float32, device=self.device)
+            self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
+            self.ema = z() if keep_ema else None
+            self.step = 0
+            sd = state_dict if state_dict is not None else {k: torch.from_numpy(np.array(v)) for k, v in synth_state_dict(denoiser_cfg, init_seed).items()}
+            self.load_state_dict(sd)
+            _lib.check(L.tld_train_bind(self._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(self.grads.data_ptr())), "tld_train_bind")
+        except Exception:
+            L.tld_train_destroy(self._h)
+            self._h = None
+            raise
+        self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    def _check_layout(self):
+        L = _lib.lib()
+        n = L.tld_train_tensor_count(self._h)
+        if n != len(self.layout) or L.tld_train_param_count(self._h) != self.numel:
+            raise RuntimeError("parameter layout of the engine and of weights.state_dict_spec disagree")
+        buf = C.create_string_buffer(256)
+        off, num = C.c_int64(), C.c_int64()
+        for i, (k, (o, s)) in enumerate(self.layout.items()):
+            _lib.check(L.tld_train_param_layout(self._h, i, buf, 256, C.byref(off), C.byref(num)), "tld_train_param_layout")
+            if buf.value.decode() != k or off.value != o or num.value != int(np.prod(s)):
+                raise RuntimeError(f"parameter layout mismatch at {i}: engine {buf.value.decode()}@{off.value}+{num.value}, host {k}@{o}")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None:
+                _lib.lib().tld_train_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- state ----------------------------------------------------------------------------------------------------------------
+    def _unflatten(self, flat: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
+        out = OrderedDict()
+        for k, (o, s) in self.layout.items():
+            out[k] = flat[o:o + int(np.prod(s))].view(*s)
+        return out
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        """Views into the live flat parameter vector, reference keys (+ the two registered buffers)."""
+        sd = self._unflatten(self.params)
+        sd["fourier_feats.0.angular_speeds"] = self._angular
+        return sd
+
+    def ema_state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        """What the reference saves as ``model_ema`` (tld/train.py:150-156) and the inference ``Denoiser`` loads."""
+        if self.ema is None:
+            raise RuntimeError("this Trainer keeps no EMA copy (keep_ema=False)")
+        sd = OrderedDict((k, v.clone()) for k, v in self._unflatten(self.ema).items())
+        sd["fourier_feats.0.angular_speeds"] = self._angular.clone()
+        sd["denoiser_trans_block.precomputed_pos_enc"] = torch.arange(self.layout["denoiser_trans_block.pos_embed.weight"][1][0])
+        return sd
+
+    def grad_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        return self._unflatten(self.grads)
+
+    def load_state_dict(self, sd: Mapping[str, torch.Tensor]) -> "Trainer":
+        missing = [k for k in self.layout if k not in sd]
+        if missing:
+            raise RuntimeError(f"missing keys in state_dict: {missing[:4]}{' ...' if len(missing) > 4 else ''}")
+        host = torch.empty(self.numel, dtype=torch.float32)
+        for k, (o, s) in self.layout.items():
+            t = (sd[k] if isinstance(sd[k], torch.Tensor) else torch.as_tensor(np.asarray(sd[k]))).detach().to(torch.float32).cpu()
+            if tuple(t.shape) != s:
+                raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(t.shape)}, model {s}")
+            host[o:o + t.numel()] = t.reshape(-1)
+        self.params.copy_(host)
+        if self.ema is not None:
+            self.ema.copy_(host)                                  # ema_model = copy.deepcopy(model)   (tld/train.py:110-111)
+        ang = sd.get("fourier_feats.0.angular_speeds")
+        if ang is None:
+            ang = torch.from_numpy(np.array(synth_state_dict(self.cfg, 0)["fourier_feats.0.angular_speeds"]))
+        self._angular = (ang if isinstance(ang, torch.Tensor) else torch.as_tensor(np.asarray(ang))).detach().to(torch.float32).cpu().contiguous()
+        a = self._angular.numpy()
+        _lib.check(_lib.lib().tld_train_set_angular_speeds(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.size), "tld_train_set_angular_speeds")
+        _lib.check(_lib.lib().tld_train_bind(self._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(self.grads.data_ptr())), "tld_train_bind")
+        return self
+
+    # ---- the step -------------------------------------------------------------------------------------------------------------
+    def make_batch(self, x: torch.Tensor, y: torch.Tensor, np_rng: Optional[np.random.Generator] = None,
+                   generator: Optional[torch.Generator] = None):
+        """tld/train.py:118-138 for one (latents, text embeddings) batch: returns (x_noisy, noise_level fp32, label)."""
+        rng = np_rng if np_rng is not None else np.random.default_rng()
+        noise_level = torch.tensor(rng.beta(self.tc.beta_a, self.tc.beta_b, len(x)))          # float64 (:120-122)
+        noise = torch.randn(x.shape, generator=generator, dtype=x.dtype)
+        mask = torch.rand(y.size(0), generator=generator) < LABEL_DROPOUT
+        return mix_noise(x, noise_level, noise), noise_level.float(), drop_labels(y, mask)
+
+    def forward_backward(self, x_noisy: torch.Tensor, noise_level: torch.Tensor, label: torch.Tensor, target: torch.Tensor):
+        """zero_grad + forward + MSE + backward (tld/train.py:163-168).  Returns (loss [1] on the device, pred); the gradients are in
+        ``self.grads`` (flat) / ``grad_dict()``."""
+        dev = self.device
+        t = lambda a: a.detach().to(dev, torch.float32).contiguous()
+        xn, nl, lab, tgt = t(x_noisy), t(noise_level).view(-1), t(label), t(target)
+        B = xn.shape[0]
+        if not (nl.numel() == B and lab.shape[0] == B and tgt.shape == xn.shape):
+            raise ValueError("inconsistent batch shapes")
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
+        pred = torch.empty_like(xn)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().tld_train_forward_backward(self._h, C.c_void_p(xn.data_ptr()), C.c_void_p(nl.data_ptr()), C.c_void_p(lab.data_ptr()),
+                                                             C.c_void_p(tgt.data_ptr()), B, C.c_void_p(self._loss.data_ptr()), C.c_void_p(pred.data_ptr()),
+                                                             C.c_void_p(stream)), "tld_train_forward_backward")
+        return self._loss, pred
+
+    def optimizer_step(self) -> None:
+        """DDP gradient mean (one all-reduce of the flat vector over RCCL) + Adam + EMA (tld/train.py:168-172)."""
+        scale = allreduce_mean_(self.grads, self.group)
+        self.step += 1
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        p = lambda a: C.c_void_p(a.data_ptr()) if a is not None else None
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().tld_train_adam_ema(self._h, p(self.params), p(self.grads), p(self.exp_avg), p(self.exp_avg_sq), p(self.ema), self.numel,
+                                                     float(self.tc.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step,
+                                                     float(self.tc.alpha), float(scale), C.c_void_p(stream)), "tld_train_adam_ema")
+
+    def train_step(self, x: torch.Tensor, y: torch.Tensor, np_rng: Optional[np.random.Generator] = None,
+                   generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        """One iteration of the reference's inner loop on the batch (x, y) as the loader yields it (x already divided by the VAE scale
+        factor, :119).  Returns the loss tensor (device, not synchronised)."""
+        x_noisy, noise_level, label = self.make_batch(x, y, np_rng, generator)
+        loss, _ = self.forward_backward(x_noisy, noise_level, label, x)
+        self.optimizer_step()
+        return loss
+
+    def checkpoint(self) -> Dict[str, object]:
+        """The dict the reference saves (tld/train.py:150-156): EMA weights, optimizer state, global step."""
+        return {"model_ema": self.ema_state_dict(),
+                "opt_state": {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step, "lr": self.tc.lr},
+                "global_step": self.step}
