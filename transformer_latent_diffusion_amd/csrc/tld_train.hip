@@ -64,6 +64,7 @@ struct LayerB {          // engine-owned per-layer buffers
     float2 *st1, *st2, *st3;
     bf16 *a1, *a2, *a3, *qk, *vt, *att, *qc, *cr, *h, *hc, *gl, *o;
     float *kvc, *p0;
+    float* dww_t;                                                            // depthwise taps, tap-major [9][hid] (refreshed with the operands)
 };
 
 inline dim3 g1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
@@ -96,6 +97,7 @@ struct tld_train {
     float* gx;                           // dL/d(residual stream) fp32 [M, d]
     bf16 *gxb, *T1, *T2, *dbig, *dsmall, *dsmall2;
     float* scr;                          // small fp32 scratch ([pd, d])
+    float* splitk;                       // split-K partials of the weight-gradient GEMMs [8][max(hid, 3d)][d]
     float* part;                         // reduction partials
     size_t part_floats = 0;
     bool weights_fresh = false;
@@ -195,7 +197,9 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
         DALLOC(e->dsmall, M * 3 * d); DALLOC(e->dsmall2, M * d); DALLOC(e->scr, (size_t)pd * d + 64);
         const size_t nchunk = (M + 255) / 256;
         size_t need = nchunk * 2 * (size_t)wide;                              // LN / colsum partials
-        if (B * 10 * (size_t)hid > need) need = B * 10 * (size_t)hid;          // depthwise weight-gradient partials
+        if (((M + 31) / 32) * 2 * (size_t)d > need) need = ((M + 31) / 32) * 2 * (size_t)d;   // LayerNorm-backward partials (32-row workgroups)
+        if (B * e->G * 10 * (size_t)hid > need) need = B * e->G * 10 * (size_t)hid;          // depthwise weight-gradient partials (per sample and image row)
+        DALLOC(e->splitk, 8 * (size_t)wide * d);
         if (nchunk * (size_t)pd * d > need) need = nchunk * (size_t)pd * d;    // tall weight-gradient partials
         e->part_floats = need;
         DALLOC(e->part, need);
@@ -207,7 +211,7 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
             DALLOC(q.x1, M * d); DALLOC(q.x2, M * d); DALLOC(q.x3, M * d); DALLOC(q.st1, M); DALLOC(q.st2, M); DALLOC(q.st3, M);
             DALLOC(q.a1, M * d); DALLOC(q.a2, M * d); DALLOC(q.a3, M * d); DALLOC(q.qk, M * 2 * d); DALLOC(q.vt, M * d); DALLOC(q.att, M * d);
             DALLOC(q.qc, M * d); DALLOC(q.cr, M * d); DALLOC(q.h, M * hid); DALLOC(q.hc, M * hid); DALLOC(q.gl, M * hid); DALLOC(q.o, M * d);
-            DALLOC(q.kvc, B * 2 * 2 * d); DALLOC(q.p0, M * e->H);
+            DALLOC(q.kvc, B * 2 * 2 * d); DALLOC(q.p0, M * e->H); DALLOC(q.dww_t, 9 * hid);
         }
         return 0;
     };
@@ -271,6 +275,7 @@ int tld_train_refresh_weights(tld_train* e, void* hip_stream) {
         both(e->lp[i].q, d, d, e->lb[i].wq, e->lb[i].wq_t);
         both(e->lp[i].up_w, hid, d, e->lb[i].wup, e->lb[i].wup_t);
         both(e->lp[i].down_w, d, hid, e->lb[i].wdown, e->lb[i].wdown_t);
+        hipLaunchKernelGGL(dw_tapmajor_kernel, g1((size_t)hid * 9), dim3(256), 0, s, e->params + e->lp[i].dw_w, e->lb[i].dww_t, hid);
     }
     HIP_TRY(hipGetLastError());
     e->weights_fresh = true;
@@ -290,13 +295,26 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
     const dim3 blk(256);
     const int nchunk = (M + 255) / 256;
     const float inv_numel = 1.0f / (float)((size_t)B * e->C * e->S * e->S);
+    // the three small fp32 products on the tiled kernel (see tld_train_kernels.h)
+    auto lin_fwd = [&](const float* in, int ldi, const float* W, const float* bias, float* out, int ldo, int R, int Nn, int K, float* pre, int gelu) {
+        hipLaunchKernelGGL(tiled_f32_kernel, dim3((Nn + 31) / 32, (R + 31) / 32), dim3(256), 0, s, in, (long)ldi, 1L, W, (long)K, 1L, bias, out, ldo, R, Nn, K, pre, gelu, 0);
+    };
+    auto lin_dx = [&](const float* dyp, int ldy, const float* W, float* dx, int ldx, int R, int Nn, int K, int acc) {      // dx[r, k] (+)= sum_n dy[r, n] W[n, k]
+        hipLaunchKernelGGL(tiled_f32_kernel, dim3((K + 31) / 32, (R + 31) / 32), dim3(256), 0, s, dyp, (long)ldy, 1L, W, 1L, (long)K, (const float*)nullptr, dx, ldx, R, K, Nn,
+                           (float*)nullptr, 0, acc);
+    };
+    auto lin_dw = [&](const float* dyp, int ldy, const float* x, int ldx, float* dW, float* db, int R, int Nn, int K) {     // dW[n, k] = sum_r dy[r, n] x[r, k]; db[n]
+        hipLaunchKernelGGL(tiled_f32_kernel, dim3((K + 31) / 32, (Nn + 31) / 32), dim3(256), 0, s, dyp, 1L, (long)ldy, x, 1L, (long)ldx, (const float*)nullptr, dW, K, Nn, K, R,
+                           (float*)nullptr, 0, 0);
+        if (db) hipLaunchKernelGGL(small_colsum, g1(Nn), dim3(256), 0, s, dyp, ldy, db, R, Nn, 0);
+    };
 
     // ================================================ forward ================================================
     // conditioning (tld/denoiser.py:105-122): sinusoid -> Linear -> GELU -> Linear | label_proj -> stack -> LayerNorm
     hipLaunchKernelGGL(sinusoid_kernel, g1((size_t)B * e->ne / 2), blk, 0, s, noise_level, e->angular, e->sinb, B, e->ne / 2);
-    hipLaunchKernelGGL(small_linear_fwd, g1((size_t)B * d), blk, 0, s, e->sinb, e->ne, P + e->ff1w, P + e->ff1b, e->g1v, d, B, d, e->ne, e->h1, 1);
-    hipLaunchKernelGGL(small_linear_fwd, g1((size_t)B * d), blk, 0, s, e->g1v, d, P + e->ff3w, P + e->ff3b, e->ycat, 2 * d, B, d, d, (float*)nullptr, 0);
-    hipLaunchKernelGGL(small_linear_fwd, g1((size_t)B * d), blk, 0, s, label, e->text, P + e->lbw, P + e->lbb, e->ycat + d, 2 * d, B, d, e->text, (float*)nullptr, 0);
+    lin_fwd(e->sinb, e->ne, P + e->ff1w, P + e->ff1b, e->g1v, d, B, d, e->ne, e->h1, 1);
+    lin_fwd(e->g1v, d, P + e->ff3w, P + e->ff3b, e->ycat, 2 * d, B, d, d, nullptr, 0);
+    lin_fwd(label, e->text, P + e->lbw, P + e->lbb, e->ycat + d, 2 * d, B, d, e->text, nullptr, 0);
     hipLaunchKernelGGL((ln_fwd_kernel<float>), dim3((2 * B + 3) / 4), blk, 0, s, e->ycat, P + e->nw, P + e->nb, (bf16*)nullptr, e->y, e->yst,
                        (const float*)nullptr, 1, 2 * B, d);
     // patch embedding (tld/denoiser.py:34-45,75-77)
@@ -320,12 +338,12 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
         hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x1, b.att, b.x2, P + p.n2w, P + p.n2b, b.a2, b.st2, M, d);
         // x = x + CA(LN2 x, y)   (:62-72,137)
         gemm_bf16(b.a2, d, b.wq, d, e->zero_bias, b.qc, M, d, d, s);
-        hipLaunchKernelGGL(small_linear_fwd, g1((size_t)2 * B * 2 * d), blk, 0, s, e->y, d, P + p.kv, (const float*)nullptr, b.kvc, 2 * d, 2 * B, 2 * d, d, (float*)nullptr, 0);
+        lin_fwd(e->y, d, P + p.kv, nullptr, b.kvc, 2 * d, 2 * B, 2 * d, d, nullptr, 0);
         hipLaunchKernelGGL(cross_fwd_kernel, dim3(B * H), blk, 0, s, b.qc, b.kvc, b.cr, b.p0, N, d);
         hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x2, b.cr, b.x3, P + p.n3w, P + p.n3b, b.a3, b.st3, M, d);
         // x = x + MLPSepConv(LN3 x)   (:89-113,138)
         gemm_bf16(b.a3, d, b.wup, d, P + p.up_b, b.h, M, hid, d, s);
-        hipLaunchKernelGGL(dwconv_kernel, g1((size_t)M * hid), blk, 0, s, b.h, P + p.dw_w, P + p.dw_b, b.hc, b.gl, B, G, hid, 0);
+        hipLaunchKernelGGL(dwconv_kernel, g1((size_t)M * hid / 8), blk, 0, s, b.h, b.dww_t, P + p.dw_b, b.hc, b.gl, B, G, hid, 0);
         gemm_bf16(b.gl, hid, b.wdown, hid, P + p.down_b, b.o, M, d, hid, s);
         bf16* xnext = i + 1 < e->L ? e->lb[i + 1].x1 : e->xfin;
         hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x3, b.o, xnext, (const float*)nullptr, (const float*)nullptr, (bf16*)nullptr, (float2*)nullptr, M, d);
@@ -337,13 +355,13 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
 
     // ================================================ backward ===============================================
     auto reduce = [&](int nparts, size_t stride, size_t part_off, float* dst, int n, int acc) {
-        hipLaunchKernelGGL(reduce_partials, g1(n), blk, 0, s, e->part + part_off, nparts, stride, dst, n, acc);
+        hipLaunchKernelGGL(reduce_partials, dim3((n + 63) / 64), dim3(1024), 0, s, e->part + part_off, nparts, stride, dst, n, acc);
     };
     auto ln_bwd_rows = [&](auto dyp, auto xp, const float2* st, const float* gamma, float* dx, int acc, float* dgamma, float* dbeta, int rows, int width) {
         using TDY = std::remove_cv_t<std::remove_pointer_t<decltype(dyp)>>;
         using TX = std::remove_cv_t<std::remove_pointer_t<decltype(xp)>>;
-        const int nb = (rows + 255) / 256;
-        hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 256, rows, width);
+        const int nb = (rows + 31) / 32;                                  // 32 rows per workgroup: >= 1024 workgroups at the training batch
+        hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows, width);
         reduce(nb, 2 * (size_t)width, 0, dgamma, width, 0);
         reduce(nb, 2 * (size_t)width, width, dbeta, width, 0);
     };
@@ -357,11 +375,22 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
         using T = std::remove_cv_t<std::remove_pointer_t<decltype(inp)>>;
         hipLaunchKernelGGL((transpose_to_bf16<T>), dim3((cols + 31) / 32, (rows + 31) / 32), blk, 0, s, inp, cols, outp, rows, rows, cols);
     };
-    // dW[Nout, Kin] = dY^T X with dY [M, Nout], X [M, Kin] (bf16): both operands transposed so that the contraction (M) is contiguous
+    // dW[Nout, Kin] = dY^T X with dY [M, Nout], X [M, Kin] (bf16): both operands transposed so that the contraction (M) is contiguous.
+    // The output is small and the contraction long, so the rows are cut into `sk` runs (split-K): the transposes write the stacked
+    // operands [split][Nout | Kin][M / sk], ONE GEMM launch multiplies every split with its own W block (GemmParams::w_batch_rows)
+    // into fp32 partials [split][Nout][Kin], and a fixed-order sum finishes (bit-reproducible).
     auto weight_grad = [&](const bf16* dY, int Nout, const bf16* X, int Kin, float* dW) {
-        transpose(dY, M, Nout, e->T1);
-        transpose(X, M, Kin, e->T2);
-        gemm_f32(e->T1, M, e->T2, M, dW, Nout, Kin, M, s);
+        int sk = 1;
+        if (Nout % 256 == 0) while (sk < 8 && (M / (sk * 2)) % 128 == 0 && M / (sk * 2) >= 1024) sk *= 2;
+        const int ms = M / sk;
+        hipLaunchKernelGGL((transpose_to_bf16<bf16>), dim3((Nout + 31) / 32, (M + 31) / 32), blk, 0, s, dY, Nout, e->T1, ms, M, Nout, sk);
+        hipLaunchKernelGGL((transpose_to_bf16<bf16>), dim3((Kin + 31) / 32, (M + 31) / 32), blk, 0, s, X, Kin, e->T2, ms, M, Kin, sk);
+        if (sk == 1) { gemm_f32(e->T1, M, e->T2, M, dW, Nout, Kin, M, s); return; }
+        GemmParams g{};
+        g.A = e->T1; g.lda = ms; g.W = e->T2; g.ldw = ms; g.M = sk * Nout; g.N = Kin; g.K = ms; g.c_f32 = e->splitk; g.ldc = Kin;
+        g.w_batch_rows = Nout; g.w_batch_stride_bytes = (unsigned)((size_t)Kin * ms * 2);
+        launch_gemm(g, EPI_F32, s);
+        hipLaunchKernelGGL(reduce_partials, dim3((Nout * Kin + 63) / 64), dim3(1024), 0, s, e->splitk, sk, (size_t)Nout * Kin, dW, Nout * Kin, 0);
     };
 
     // out_proj: gx = dout Wout;  dWout = dout^T x_final;  dbout
@@ -378,18 +407,18 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
         colsum(e->gxb, M, d, Gd + p.down_b);
         weight_grad(e->gxb, d, b.gl, hid, Gd + p.down_w);
         gemm_bf16(e->gxb, d, b.wdown_t, d, e->zero_bias, e->dbig, M, hid, d, s);                         // dg = go Wdown
-        hipLaunchKernelGGL(gelu_bwd_kernel, g1((size_t)M * hid), blk, 0, s, e->dbig, b.hc, e->dbig, (size_t)M * hid);      // dhc (in place)
-        hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((hid + 255) / 256, B), blk, 0, s, e->dbig, b.h, e->part, G, hid);
-        hipLaunchKernelGGL(dwconv_wgrad_reduce, g1((size_t)hid * 10), blk, 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B, hid);
-        hipLaunchKernelGGL(dwconv_kernel, g1((size_t)M * hid), blk, 0, s, e->dbig, P + p.dw_w, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1);   // dh -> b.gl (its forward value is consumed)
+        hipLaunchKernelGGL(gelu_bwd_kernel, g1((size_t)M * hid / 8), blk, 0, s, e->dbig, b.hc, e->dbig, (size_t)M * hid / 8);      // dhc (in place)
+        hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((hid + 255) / 256, B * G), blk, 0, s, e->dbig, b.h, e->part, G, hid);
+        hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 10 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B * G, hid);
+        hipLaunchKernelGGL(dwconv_kernel, g1((size_t)M * hid / 8), blk, 0, s, e->dbig, b.dww_t, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1);   // dh -> b.gl (its forward value is consumed)
         colsum(b.gl, M, hid, Gd + p.up_b);
         weight_grad(b.gl, hid, b.a3, d, Gd + p.up_w);
         gemm_bf16(b.gl, hid, b.wup_t, hid, e->zero_bias, e->dsmall2, M, d, hid, s);                     // da3 = dh Wup
         ln_bwd_rows(e->dsmall2, b.x3, b.st3, P + p.n3w, e->gx, 1, Gd + p.n3w, Gd + p.n3b, M, d);
         // ---- cross-attention: cr = CA(qc, kv);  qc = a2 Wq^T;  kv = y Wkv^T;  a2 = LN2(x2)
         hipLaunchKernelGGL(cross_bwd_kernel, dim3(B * H), blk, (size_t)2 * N * 4, s, e->gx, b.qc, b.kvc, b.p0, e->dsmall2, e->dkv, N, d);   // dqc -> dsmall2
-        hipLaunchKernelGGL(small_linear_dw, g1((size_t)2 * d * d), blk, 0, s, e->dkv, 2 * d, e->y, d, Gd + p.kv, (float*)nullptr, 2 * B, 2 * d, d, 0);
-        hipLaunchKernelGGL(small_linear_dx, g1((size_t)2 * B * d), blk, 0, s, e->dkv, 2 * d, P + p.kv, e->dy, d, 2 * B, 2 * d, d, 1);
+        lin_dw(e->dkv, 2 * d, e->y, d, Gd + p.kv, nullptr, 2 * B, 2 * d, d);
+        lin_dx(e->dkv, 2 * d, P + p.kv, e->dy, d, 2 * B, 2 * d, d, 1);
         weight_grad(e->dsmall2, d, b.a2, d, Gd + p.q);
         gemm_bf16(e->dsmall2, d, b.wq_t, d, e->zero_bias, e->dsmall, M, d, d, s);                       // da2 = dqc Wq
         ln_bwd_rows(e->dsmall, b.x2, b.st2, P + p.n2w, e->gx, 1, Gd + p.n2w, Gd + p.n2b, M, d);
@@ -403,7 +432,7 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
     hipLaunchKernelGGL(pos_grad_kernel, g1((size_t)N * d), blk, 0, s, e->gx, Gd + e->pos, B, N, d);
     ln_bwd_rows(e->gx, e->e, e->est2, P + e->l2w, e->de, 0, Gd + e->l2w, Gd + e->l2b, M, d);
     colsum(e->de, M, d, Gd + e->lib);
-    hipLaunchKernelGGL(small_linear_dx, g1((size_t)M * pd), blk, 0, s, e->de, d, P + e->liw, e->dpn, pd, M, d, pd, 0);               // dpn = de Wlin
+    lin_dx(e->de, d, P + e->liw, e->dpn, pd, M, d, pd, 0);               // dpn = de Wlin
     hipLaunchKernelGGL((tall_dw_partial<float>), dim3((pd * d + 255) / 256, nchunk), blk, 0, s, e->p16n, pd, e->de, d, M, 256, e->part);
     reduce(nchunk, (size_t)pd * d, 0, e->scr, pd * d, 0);                                                                              // dWlin^T [pd, d]
     hipLaunchKernelGGL(transpose_f32_small, g1((size_t)pd * d), blk, 0, s, e->scr, Gd + e->liw, pd, d);
@@ -416,11 +445,11 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
     colsum(e->dp16, M, pd, Gd + e->cvb);
     // ---- conditioning: y = LN(stack[nz, lb]);  nz = W3 GELU(W1 sin + b1) + b3;  lb = label_proj(label)     (tld/denoiser.py:105-122)
     ln_bwd_rows(e->dy, e->ycat, e->yst, P + e->nw, e->dycat, 0, Gd + e->nw, Gd + e->nb, 2 * B, d);
-    hipLaunchKernelGGL(small_linear_dw, g1((size_t)d * e->text), blk, 0, s, e->dycat + d, 2 * d, label, e->text, Gd + e->lbw, Gd + e->lbb, B, d, e->text, 0);
-    hipLaunchKernelGGL(small_linear_dw, g1((size_t)d * d), blk, 0, s, e->dycat, 2 * d, e->g1v, d, Gd + e->ff3w, Gd + e->ff3b, B, d, d, 0);
-    hipLaunchKernelGGL(small_linear_dx, g1((size_t)B * d), blk, 0, s, e->dycat, 2 * d, P + e->ff3w, e->dg1, d, B, d, d, 0);
+    lin_dw(e->dycat + d, 2 * d, label, e->text, Gd + e->lbw, Gd + e->lbb, B, d, e->text);
+    lin_dw(e->dycat, 2 * d, e->g1v, d, Gd + e->ff3w, Gd + e->ff3b, B, d, d);
+    lin_dx(e->dycat, 2 * d, P + e->ff3w, e->dg1, d, B, d, d, 0);
     hipLaunchKernelGGL(mul_gelu_grad, g1((size_t)B * d), blk, 0, s, e->dg1, e->h1, B * d);
-    hipLaunchKernelGGL(small_linear_dw, g1((size_t)d * e->ne), blk, 0, s, e->dg1, d, e->sinb, e->ne, Gd + e->ff1w, Gd + e->ff1b, B, d, e->ne, 0);
+    lin_dw(e->dg1, d, e->sinb, e->ne, Gd + e->ff1w, Gd + e->ff1b, B, d, e->ne);
     HIP_TRY(hipGetLastError());
     return TLD_OK;
 }

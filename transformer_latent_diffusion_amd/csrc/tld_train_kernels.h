@@ -23,45 +23,58 @@ __device__ __forceinline__ float gelu_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
-// ---- small fp32 linears (conditioning path, out-projection pieces: R rows <= a few hundred or N, K small) --------------------------
-// out[r, n] = act(b[n] + sum_k in[r, k] W[n, k])
-__global__ void small_linear_fwd(const float* __restrict__ in, int ldi, const float* __restrict__ W, const float* __restrict__ b,
-                                 float* __restrict__ out, int ldo, int R, int N, int K, float* __restrict__ pre /*nullable: pre-activation*/, int gelu) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= R * N) return;
-    const int r = idx / N, n = idx - r * N;
-    float a = b ? b[n] : 0.f;
-    const float* x = in + (size_t)r * ldi;
-    const float* w = W + (size_t)n * K;
-    for (int k = 0; k < K; ++k) a = fmaf(x[k], w[k], a);
-    if (pre) pre[(size_t)r * ldo + n] = a;
-    out[(size_t)r * ldo + n] = gelu ? gelu_exact(a) : a;
-}
-// dx[r, k] (+)= sum_n dy[r, n] W[n, k]
-__global__ void small_linear_dx(const float* __restrict__ dy, int ldy, const float* __restrict__ W, float* __restrict__ dx, int ldx,
-                                int R, int N, int K, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= R * K) return;
-    const int r = idx / K, k = idx - r * K;
-    float a = 0.f;
-    for (int n = 0; n < N; ++n) a = fmaf(dy[(size_t)r * ldy + n], W[(size_t)n * K + k], a);
-    float* o = dx + (size_t)r * ldx + k;
-    *o = accumulate ? *o + a : a;
-}
-// dW[n, k] (+)= sum_r dy[r, n] x[r, k];  db[n] (+)= sum_r dy[r, n]
-__global__ void small_linear_dw(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx, float* __restrict__ dW,
-                                float* __restrict__ db, int R, int N, int K, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * K) return;
-    const int n = idx / K, k = idx - n * K;
-    float a = 0.f, s = 0.f;
-    for (int r = 0; r < R; ++r) {
-        const float g = dy[(size_t)r * ldy + n];
-        a = fmaf(g, x[(size_t)r * ldx + k], a);
-        s += g;
+// ---- small fp32 products (conditioning path, kv projection of the cross-attention, out-projection pieces) ------------------------------
+// C[i, j] (+)= bias[j] + sum_k A(i, k) B(j, k)   with   A(i, k) = A[i sai + k sak],  B(j, k) = B[j sbj + k sbk]:  one kernel serves
+//   forward   out[r, n] = b[n] + sum_k in[r, k] W[n, k]            (A = in, B = W)
+//   dx[r, k'] = sum_n dy[r, n] W[n, k']                            (A = dy, B(k', n) = W[n K + k'])
+//   dW[n, k'] = sum_r dy[r, n] x[r, k']                            (A(n, r) = dy[r ldy + n], B(k', r) = x[r ldx + k'])
+// 32 x 32 output tile per 256-thread workgroup (2 x 2 per thread), 32-deep K-steps through LDS; exact fp32 FMA chains in k order.
+__global__ __launch_bounds__(256) void tiled_f32_kernel(const float* __restrict__ A, long sai, long sak, const float* __restrict__ B, long sbj, long sbk,
+                                                        const float* __restrict__ bias, float* __restrict__ C, int ldc, int I, int J, int K,
+                                                        float* __restrict__ pre, int gelu, int accumulate) {
+    __shared__ float sa[32][33], sb[32][33];
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int t = threadIdx.x; t < 1024; t += 256) {
+            // the faster-varying index of a load follows the operand's unit stride so that both layouts read coalesced
+            int ii, kk;
+            if (sak == 1) { kk = t & 31; ii = t >> 5; } else { ii = t & 31; kk = t >> 5; }
+            sa[kk][ii] = (i0 + ii < I && k0 + kk < K) ? A[(long)(i0 + ii) * sai + (long)(k0 + kk) * sak] : 0.f;
+            int jj, k2;
+            if (sbk == 1) { k2 = t & 31; jj = t >> 5; } else { jj = t & 31; k2 = t >> 5; }
+            sb[k2][jj] = (j0 + jj < J && k0 + k2 < K) ? B[(long)(j0 + jj) * sbj + (long)(k0 + k2) * sbk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const float a0 = sa[kk][ty * 2], a1 = sa[kk][ty * 2 + 1], b0 = sb[kk][tx * 2], b1 = sb[kk][tx * 2 + 1];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
     }
-    dW[idx] = accumulate ? dW[idx] + a : a;
-    if (db && k == 0) db[n] = accumulate ? db[n] + s : s;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int i = i0 + ty * 2 + a, j = j0 + tx * 2 + b;
+            if (i >= I || j >= J) continue;
+            float v = acc[a][b] + (bias ? bias[j] : 0.f);
+            float* o = C + (size_t)i * ldc + j;
+            if (pre) pre[(size_t)i * ldc + j] = v;
+            if (gelu) v = gelu_exact(v);
+            *o = accumulate ? *o + v : v;
+        }
+}
+// db[n] (+)= sum_r dy[r, n]
+__global__ void small_colsum(const float* __restrict__ dy, int ldy, float* __restrict__ db, int R, int N, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += dy[(size_t)r * ldy + n];
+    db[n] = accumulate ? db[n] + s : s;
 }
 __global__ void mul_gelu_grad(float* __restrict__ g, const float* __restrict__ pre, int n) {     // g *= GELU'(pre)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,13 +153,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         part[((size_t)blockIdx.x * 2 + 1) * d + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
     }
 }
-// out[c] (+)= sum_i part[i * stride + c]   (fixed order: bit-reproducible)
-__global__ void reduce_partials(const float* __restrict__ part, int nparts, size_t stride, float* __restrict__ out, int n, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
+// out[c] (+)= sum_i part[i * stride + c]   (fixed order: bit-reproducible).  64 columns x 16 part-lanes per workgroup: lane l sums the parts
+// l, l + 16, ... and an LDS tree finishes -- the outputs are few (a weight's size), the parts up to thousands.
+__global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ part, int nparts, size_t stride, float* __restrict__ out, int n, int accumulate) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     float a = 0.f;
-    for (int i = 0; i < nparts; ++i) a += part[(size_t)i * stride + c];
-    out[c] = accumulate ? out[c] + a : a;
+    if (c < n) for (int i = ty; i < nparts; i += 16) a += part[(size_t)i * stride + c];
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && c < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l][tx];
+        out[c] = accumulate ? out[c] + t : t;
+    }
+}
+// [C][9] -> [9][C]  (tap-major copy of a depthwise weight)
+__global__ void dw_tapmajor_kernel(const float* __restrict__ w, float* __restrict__ out, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * 9) return;
+    const int c = i / 9, k = i - c * 9;
+    out[(size_t)k * C + c] = w[i];
 }
 // column sums of a [M, C] matrix over row chunks: part[chunk][C]
 template <typename T>
@@ -237,7 +266,9 @@ __global__ __launch_bounds__(256) void resid_add_ln_kernel(const bf16* __restric
 // ---- layout helpers -----------------------------------------------------------------------------------------------------------
 // [R, C] -> [C, R] (bf16 out), 32 x 32 tiles through LDS;  TIN = bf16 or float (rounded once)
 template <typename TIN>
-__global__ __launch_bounds__(256) void transpose_to_bf16(const TIN* __restrict__ in, int ldi, bf16* __restrict__ out, int ldo, int R, int C) {
+__global__ __launch_bounds__(256) void transpose_to_bf16(const TIN* __restrict__ in, int ldi, bf16* __restrict__ out, int ldo, int R, int C, int splits = 1) {
+    // splits > 1 (split-K operand of a weight-gradient GEMM): the R rows are cut into `splits` equal runs and the output is the stack
+    // [split][C][R / splits] -- ldo = R / splits then
     __shared__ float tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
@@ -246,9 +277,13 @@ __global__ __launch_bounds__(256) void transpose_to_bf16(const TIN* __restrict__
         tile[i][tx] = (r < R && c < C) ? ldf(in + (size_t)r * ldi + c) : 0.f;
     }
     __syncthreads();
+    const int rs = R / splits;
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
-        if (c < C && r < R) out[(size_t)c * ldo + r] = (bf16)tile[tx][i];
+        if (c < C && r < R) {
+            const int sp = r / rs;
+            out[((size_t)sp * C + c) * ldo + (r - sp * rs)] = (bf16)tile[tx][i];
+        }
     }
 }
 __global__ void cast_f32_bf16(const float* __restrict__ in, bf16* __restrict__ out, size_t n) {
@@ -412,66 +447,103 @@ __global__ void cross_bwd_kernel(const float* __restrict__ g, const bf16* __rest
 }
 
 // ---- depthwise 3x3 (zero "same" padding, cross-correlation) + GELU (tld/transformer_blocks.py:96-103) --------------------------------
-// channels-last image [B, G, G, C] == token-major [M, C].  w [C, 3, 3] fp32 (the reference's [C, 1, 3, 3]).
+// channels-last image [B, G, G, C] == token-major [M, C].  w: TAP-MAJOR copy [9][C] fp32 of the reference's [C, 1, 3, 3] (refreshed with the
+// bf16 GEMM operands), so that a thread's 8 channels are two 16-byte loads per tap.
 // forward (flip = 0): out = b + sum_taps w[c][ky][kx] in[y + ky - 1][x + kx - 1];  also gelu_out = GELU(out) when given.
 // input gradient (flip = 1, no bias): din[y][x] = sum_taps w[c][ky][kx] dout[y - ky + 1][x - kx + 1]
-__global__ void dwconv_kernel(const bf16* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, bf16* __restrict__ out,
-                              bf16* __restrict__ gelu_out, int B, int G, int C, int flip) {
+__global__ __launch_bounds__(256) void dwconv_kernel(const bf16* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, bf16* __restrict__ out,
+                                                     bf16* __restrict__ gelu_out, int B, int G, int C, int flip) {
+    // one thread: 8 consecutive channels of one position (16-byte accesses; the 9 taps of a position are L1 / L2 hits)
+    const int C8 = C >> 3;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * G * G * C) return;
-    const int c = (int)(i % C);
-    const size_t m = i / C;
+    if (i >= (size_t)B * G * G * C8) return;
+    const int c0 = (int)(i % C8) * 8;
+    const size_t m = i / C8;
     const int x = (int)(m % G), y = (int)((m / G) % G);
     const size_t b = m / ((size_t)G * G);
-    float a = (bias && !flip) ? bias[c] : 0.f;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = (bias && !flip) ? bias[c0 + e] : 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int yy = flip ? y - ky + 1 : y + ky - 1, xx = flip ? x - kx + 1 : x + kx - 1;
-            if ((unsigned)yy < (unsigned)G && (unsigned)xx < (unsigned)G)
-                a = fmaf(w[c * 9 + ky * 3 + kx], (float)in[((b * G + yy) * G + xx) * C + c], a);
+            if ((unsigned)yy < (unsigned)G && (unsigned)xx < (unsigned)G) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(in + ((b * G + yy) * G + xx) * C + c0);
+                const float4 wa = *reinterpret_cast<const float4*>(w + (size_t)(ky * 3 + kx) * C + c0);
+                const float4 wb = *reinterpret_cast<const float4*>(w + (size_t)(ky * 3 + kx) * C + c0 + 4);
+                const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = fmaf(wv[e], (float)v[e], a[e]);
+            }
         }
-    out[i] = (bf16)a;
-    if (gelu_out) gelu_out[i] = (bf16)gelu_exact((float)(bf16)a);        // GELU of the STORED pre-activation: what the backward differentiates
+    bf16x8 o, g;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { o[e] = (bf16)a[e]; g[e] = (bf16)gelu_exact((float)o[e]); }      // GELU of the STORED pre-activation: what the backward differentiates
+    *reinterpret_cast<bf16x8*>(out + m * C + c0) = o;
+    if (gelu_out) *reinterpret_cast<bf16x8*>(gelu_out + m * C + c0) = g;
 }
 // dhc = dg * GELU'(hc)
-__global__ void gelu_bwd_kernel(const bf16* __restrict__ dg, const bf16* __restrict__ hc, bf16* __restrict__ out, size_t n) {
+__global__ void gelu_bwd_kernel(const bf16* __restrict__ dg, const bf16* __restrict__ hc, bf16* __restrict__ out, size_t n8) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (bf16)((float)dg[i] * gelu_grad((float)hc[i]));
+    if (i >= n8) return;
+    const bf16x8 g = reinterpret_cast<const bf16x8*>(dg)[i], h = reinterpret_cast<const bf16x8*>(hc)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)g[e] * gelu_grad((float)h[e]));
+    reinterpret_cast<bf16x8*>(out)[i] = o;
 }
-// weight / bias gradient partials per sample: part[b][10][C]: taps 0..8, then the bias;  thread per channel
+// weight / bias gradient partials per (sample, image row): part[b G + y][10][C]: taps 0..8, then the bias;  thread per channel, a 3 x 3
+// register window of `in` slides along x (3 new loads per position instead of 9)
 __global__ void dwconv_wgrad_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ in, float* __restrict__ part, int G, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const size_t b = blockIdx.y;
+    const size_t by = blockIdx.y;                 // b * G + y
+    const int y = (int)(by % G);
+    const size_t b = by / G;
     float acc[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-    for (int y = 0; y < G; ++y)
-        for (int x = 0; x < G; ++x) {
-            const float gv = (float)dout[((b * G + y) * G + x) * C + c];
-            acc[9] += gv;
+    auto ld = [&](int yy, int xx) -> float {
+        return ((unsigned)yy < (unsigned)G && (unsigned)xx < (unsigned)G) ? (float)in[((b * G + yy) * G + xx) * C + c] : 0.f;
+    };
+    float w0[3], w1[3], w2[3];                     // columns x - 1, x, x + 1 of rows y - 1 .. y + 1
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+    for (int r = 0; r < 3; ++r) { w0[r] = 0.f; w1[r] = ld(y + r - 1, 0); }
+    for (int x = 0; x < G; ++x) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int yy = y + ky - 1, xx = x + kx - 1;
-                    if ((unsigned)yy < (unsigned)G && (unsigned)xx < (unsigned)G)
-                        acc[ky * 3 + kx] = fmaf(gv, (float)in[((b * G + yy) * G + xx) * C + c], acc[ky * 3 + kx]);
-                }
+        for (int r = 0; r < 3; ++r) w2[r] = ld(y + r - 1, x + 1);
+        const float gv = (float)dout[((b * G + y) * G + x) * C + c];
+        acc[9] += gv;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            acc[r * 3 + 0] = fmaf(gv, w0[r], acc[r * 3 + 0]);
+            acc[r * 3 + 1] = fmaf(gv, w1[r], acc[r * 3 + 1]);
+            acc[r * 3 + 2] = fmaf(gv, w2[r], acc[r * 3 + 2]);
         }
 #pragma unroll
-    for (int k = 0; k < 10; ++k) part[(b * 10 + k) * C + c] = acc[k];
+        for (int r = 0; r < 3; ++r) { w0[r] = w1[r]; w1[r] = w2[r]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) part[(by * 10 + k) * C + c] = acc[k];
 }
-// dw [C, 9] / db [C] from part[B][10][C]
-__global__ void dwconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int B, int C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * 10) return;
-    const int c = i % C, k = i / C;
+// dw [C, 9] / db [C] from part[nparts][10][C]  (64 (tap, channel) outputs x 16 part-lanes per workgroup, fixed order)
+__global__ __launch_bounds__(1024) void dwconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nparts, int C) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;                 // over 10 * C, channel fastest
     float a = 0.f;
-    for (int b = 0; b < B; ++b) a += part[((size_t)b * 10 + k) * C + c];
-    if (k < 9) dw[c * 9 + k] = a; else db[c] = a;
+    if (i < 10 * C) for (int p = ty; p < nparts; p += 16) a += part[(size_t)p * 10 * C + i];
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && i < 10 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l][tx];
+        const int c = i % C, k = i / C;
+        if (k < 9) dw[c * 9 + k] = t; else db[c] = t;
+    }
 }
 
 // ---- output projection + unpatchify + loss (tld/denoiser.py:47-52,72,82; tld/train.py:167) -----------------------------------------------
