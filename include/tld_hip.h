@@ -32,7 +32,7 @@ typedef struct tld_config {
     int32_t image_size;
     int32_t noise_embed_dims;
     int32_t patch_size;
-    int32_t embed_dim;        /* multiple of 128, <= 1024: heads = embed_dim / 64, head_dim = 64 */
+    int32_t embed_dim;        /* multiple of 128, <= 896 (inference engine; the row kernels' LDS tables) / <= 1024 (training): heads = embed_dim / 64 */
     int32_t n_layers;
     int32_t text_emb_size;
     int32_t n_channels;

@@ -17,6 +17,7 @@ there is no CPU path.  A fresh object holds deterministic random weights (no che
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from collections import OrderedDict
 from dataclasses import dataclass
 from typing import Mapping, Optional, Tuple
@@ -100,6 +101,7 @@ class ClipTextEncoder:
         self._spec = clip_text_spec(self.config)
         self._state: "OrderedDict[str, torch.Tensor]" = OrderedDict(
             (k, torch.from_numpy(v)) for k, v in synth_clip_state_dict(self.config, init_seed).items())
+        self._weights_loaded = False     # still on the deterministic random initialisation (no checkpoint can be downloaded here)
         self.max_batch = int(max_batch)
         self._device: Optional[torch.device] = None
         self._engine = None
@@ -140,6 +142,7 @@ class ClipTextEncoder:
         if strict and missing:
             raise RuntimeError(f"missing keys in CLIP state_dict: {missing[:4]}{' ...' if len(missing) > 4 else ''}")
         self._state.update(new)
+        self._weights_loaded = True
         self._drop_engine()
         return self
 
@@ -190,6 +193,10 @@ class ClipTextEncoder:
         dev = text.device if text.device.type == "cuda" else (self._device or text.device)
         if dev.type != "cuda":
             raise RuntimeError("ClipTextEncoder.encode_text needs a HIP device (tokens on 'cuda'); there is no CPU path")
+        if not self._weights_loaded:
+            self._weights_loaded = True             # (warn once per object)
+            warnings.warn("ClipTextEncoder is encoding with its deterministic RANDOM initialisation: no CLIP state_dict was loaded "
+                          "(load_state_dict); the embeddings carry no meaning", RuntimeWarning, stacklevel=2)
         self._ensure_engine(dev)
         tok = text.to(dev).to(torch.int32).contiguous()
         eot = tok.argmax(dim=-1).to(torch.int32).contiguous()            # clip/model.py: "take features from the eot embedding"

@@ -513,12 +513,10 @@ template <int KT, int NW, int QT, bool PIPE>
 void launch_attn1(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
     constexpr int KC = KT * 32;
     const int lds = KC * 128 + 64 * (KC * 2 + 8) + (TLD_ATTN_ST16 == 2 ? NW * 16 * 144 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (attr_set.first())
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn1_kernel<KT, NW, QT, PIPE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
     hipLaunchKernelGGL((attn1_kernel<KT, NW, QT, PIPE>), dim3(1, heads, batch), dim3(NW * 64), lds, s, qk, vt, att, ntok,
                        heads * 64);
 }
@@ -529,12 +527,10 @@ void launch_kt(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, i
     static const bool dbuf_on = !(getenv("TLD_ATTN_DBUF") && atoi(getenv("TLD_ATTN_DBUF")) == 0);     // A/B knob
     const int nbuf = (ntok > KC && dbuf_on && 2 * (KC * 128 + 64 * (KC * 2 + 8)) <= 160 * 1024) ? 2 : 1;
     const int lds = nbuf * (KC * 128 + 64 * (KC * 2 + 8));
-    static int attr_lds = 0;
-    if (attr_lds < lds) {
+    static PerDeviceMax attr_lds;
+    if (attr_lds.raise(lds))
         hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<KT, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_lds = lds;
-    }
     dim3 grid(ntok / (NW * 32), heads, batch), block(NW * 64);
     hipLaunchKernelGGL((attn_kernel<KT, NW>), grid, block, lds, s, qk, vt, att, ntok, heads * 64, nbuf);
 }

@@ -369,8 +369,8 @@ int tld_clip_encode_text(tld_clip* c, const int32_t* tokens, const int32_t* eot_
     }
     const dim3 rows((T + 3) / 4);
     const size_t attn_lds = (size_t)(ctx * 64 * 2 + ctx * 65 + 128) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) { hipFuncSetAttribute(reinterpret_cast<const void*>(clip_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (64 * 2 + 65) * 4 + 512); attr_set = true; }
+    static PerDeviceOnce attr_set;
+    if (attr_set.first()) hipFuncSetAttribute(reinterpret_cast<const void*>(clip_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (64 * 2 + 65) * 4 + 512);
     hipLaunchKernelGGL(clip_add_ln_kernel, rows, dim3(256), 0, s, c->x, (const float*)nullptr, (const float*)nullptr, c->blocks[0].ln1_g, c->blocks[0].ln1_b, c->h, T, W);
     for (int l = 0; l < c->L; ++l) {
         const Block& b = c->blocks[l];
@@ -398,6 +398,11 @@ int tld_clip_read_buffer(tld_clip* c, const char* name, float* host_out, int64_t
     DeviceGuard guard(c->cfg.device_id);
     HIP_TRY(hipDeviceSynchronize());
     const std::string n(name);
+    {   // bound the read by the buffer's size (workspace is sized for max_batch * context_length rows)
+        const int64_t TW = (int64_t)c->cfg.max_batch * c->ctx * c->W;
+        const int64_t cap = n == "pooled" ? (int64_t)c->cfg.max_batch * c->W : n == "qkv" ? 3 * TW : n == "f" ? 4 * TW : TW;
+        if (numel <= 0 || numel > cap) return fail(TLD_ERR_INVALID, "numel %lld outside (0, %lld] for buffer '%s'", (long long)numel, (long long)cap, name);
+    }
     const float* f32 = n == "x" ? c->x : n == "tmp" ? c->tmp : n == "pooled" ? c->pooled : nullptr;
     const bf16* b16 = n == "h" ? c->h : n == "qkv" ? c->qkv : n == "att" ? c->att : n == "f" ? c->f : nullptr;
     if (f32) { HIP_TRY(hipMemcpy(host_out, f32, (size_t)numel * 4, hipMemcpyDeviceToHost)); return TLD_OK; }

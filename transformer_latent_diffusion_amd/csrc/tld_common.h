@@ -226,6 +226,59 @@ enum GemmEpilogue {
     EPI_UP_DWCONV2 = 6,  // the same fusion on a token-pair image with packed-bf16 taps (v_dot2c_f32_bf16), see tld_gemm.hip
 };
 
+// Launch-side caches are PER DEVICE: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current device only, and engines on
+// different devices may live in one process (every ABI entry point runs under a device guard).
+struct PerDeviceOnce {
+    unsigned long long mask = 0;
+    bool first() {                                   // true once per device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (mask & bit) return false;
+        mask |= bit;
+        return true;
+    }
+};
+struct PerDeviceMax {                                // largest value requested so far on the current device
+    int v[64] = {0};
+    bool raise(int want) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (v[dev & 63] >= want) return false;
+        v[dev & 63] = want;
+        return true;
+    }
+};
+// device that owns a device pointer (debug hooks that take raw pointers and no engine); -1 if unknown
+inline int ptr_device(const void* p) {
+    hipPointerAttribute_t a;
+    if (p && hipPointerGetAttributes(&a, p) == hipSuccess) return a.device;
+    (void)hipGetLastError();
+    return -1;
+}
+struct PtrDeviceGuard {                              // runs the scope on the pointer's device, restores the caller's device after
+    int prev = -1; bool switched = false;
+    explicit PtrDeviceGuard(const void* p) {
+        const int dev = ptr_device(p);
+        if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~PtrDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    PtrDeviceGuard(const PtrDeviceGuard&) = delete;
+    PtrDeviceGuard& operator=(const PtrDeviceGuard&) = delete;
+};
+inline int device_cu_count() {
+    static int cus[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& c = cus[dev & 63];
+    if (!c) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        c = n;
+    }
+    return c;
+}
+
 struct GemmParams {
     const bf16* A; int lda;       // [M,K] row-major, K contiguous
     const bf16* W; int ldw;       // [N,K] row-major (nn.Linear weight layout)

@@ -424,9 +424,9 @@ const char* tld_last_error(void) { return g_err; }
 int tld_engine_create(const tld_config* c, tld_engine** out) {
     if (!c || !out) return fail(TLD_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (c->embed_dim <= 0 || c->embed_dim % 128 != 0 || c->embed_dim > 1024)
-        return fail(TLD_ERR_INVALID, "embed_dim=%d unsupported: must be a multiple of 128, <= 1024 "
-                    "(head_dim is 64 and row kernels own 128-feature groups)", c->embed_dim);
+    if (c->embed_dim <= 0 || c->embed_dim % 128 != 0 || c->embed_dim > 896)
+        return fail(TLD_ERR_INVALID, "embed_dim=%d unsupported: must be a multiple of 128, <= 896 "
+                    "(head_dim is 64, row kernels own 128-feature groups and keep per-workgroup tables in <= 64 KiB of LDS)", c->embed_dim);
     if (c->patch_size <= 0 || c->image_size % c->patch_size != 0)
         return fail(TLD_ERR_INVALID, "image_size=%d must be divisible by patch_size=%d", c->image_size, c->patch_size);
     const int grid = c->image_size / c->patch_size, ntok = grid * grid;
@@ -953,6 +953,7 @@ int tld_debug_quant_mx8_host(const float* w, int32_t rows, int32_t K, void* out_
 
 int tld_debug_quant_mx8(const void* in_bf16, void* out_e4m3, void* out_scale, int32_t M, int32_t K, void* hip_stream) {
     if (!in_bf16 || !out_e4m3 || !out_scale || M <= 0 || K <= 0 || K % 128) return fail(TLD_ERR_INVALID, "bad argument (K %% 128 == 0)");
+    PtrDeviceGuard guard(in_bf16);
     launch_quant_mx8(static_cast<const bf16*>(in_bf16), static_cast<uint8_t*>(out_e4m3), static_cast<uint8_t*>(out_scale), M, K,
                      static_cast<hipStream_t>(hip_stream));
     HIP_TRY(hipGetLastError());
@@ -963,6 +964,7 @@ int tld_debug_gemm_mx8(const void* a_e4m3, const void* a_scale, const void* w_e4
                        int32_t N, int32_t K, void* hip_stream) {
     if (!a_e4m3 || !a_scale || !w_e4m3 || !w_scale || !c) return fail(TLD_ERR_INVALID, "null argument");
     if (K % 128 || K <= 0 || M <= 0 || N <= 0 || M % 4 || N % 4) return fail(TLD_ERR_INVALID, "need K %% 128 == 0, M %% 4 == 0, N %% 4 == 0");
+    PtrDeviceGuard guard(a_e4m3);
     GemmParams g{};
     g.f8 = 1;
     g.A = static_cast<const bf16*>(a_e4m3); g.lda = K; g.W = static_cast<const bf16*>(w_e4m3); g.ldw = K;

@@ -1290,12 +1290,7 @@ template <int BN>
 void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     using G = G256P<BN>;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + G::BM - 1) / G::BM;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0; hipGetDevice(&dev);
-        hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int ncu = device_cu_count();
     const int nblocks = ntm * ntn < ncu ? ntm * ntn : ncu;
     dim3 grid(nblocks), block(512);
     // Up-projection (12 tile-columns at d = 768): two column groups x four tile-row blocks over the 8 XCDs keep each
@@ -1314,12 +1309,10 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
 #define TLD_L256P_(E, F8) TLD_L256P__(E, F8, false)
 #define TLD_L256P_LAUNCH(E, F8, CV, RG)                                                               \
     do {                                                                                              \
-        static bool once = false;                                                                     \
-        if (!once) {                                                                                  \
+        static PerDeviceOnce once;                                                                    \
+        if (once.first())                                                                             \
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E, F8, CV, RG>),    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
-            once = true;                                                                              \
-        }                                                                                             \
         hipLaunchKernelGGL((gemm256p_kernel<BN, E, F8, CV, RG>), grid, block, lds, s, pg, nblocks);   \
     } while (0)
 #define TLD_L256P__(E, F8, CV)                                                                        \

@@ -956,7 +956,7 @@ void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf1
     TLD_DISPATCH_NJ(d / 128, hipLaunchKernelGGL(layernorm_bf16_kernel<NJ>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d));
 }
 
-bool layernorm_mx8_supported(int d) { return d == 256 || d == 512 || d == 768 || d == 1024; }
+bool layernorm_mx8_supported(int d) { return d == 256 || d == 512 || d == 768; }      // (the engine's embed_dim limit is 896)
 
 void launch_layernorm_mx8(const resid_t* x, const float* g, const float* b, uint8_t* out8, uint8_t* scale8, int M, int d,
                           hipStream_t s) {
@@ -977,12 +977,7 @@ void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
     // ~43 KB of LDS per workgroup -> 3 workgroups per CU.  Split each sample's row pairs into the number of
     // chunks that makes the grid ONE full resident round (768 workgroups on 256 CUs) when the batch allows,
     // else k rounds of <= ~48 rows per workgroup; a partial extra round costs as much as a full one.
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        slots = 3 * (cus > 0 ? cus : 256);
-    }
+    const int slots = 3 * device_cu_count();
     const long rows = (long)p.batch * p.ntok;
     const long k = (rows + (long)slots * 48 - 1) / ((long)slots * 48);
     long cps = slots * k / p.batch;

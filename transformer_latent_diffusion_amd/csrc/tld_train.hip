@@ -474,6 +474,7 @@ int tld_train_adam_ema(tld_train* e, float* params, const float* grads, float* e
  * bf16, o [M, d] bf16 (the forward output), g [M, d] fp32 (dL/dO); dqkv [M, 3 d] bf16 out (dq | dk | dv).  Device pointers. */
 int tld_debug_attention_bwd(const void* qk, const void* vt, const void* o, const float* g, void* dqkv, int32_t batch, int32_t heads, void* hip_stream) {
     if (!qk || !vt || !o || !g || !dqkv || batch <= 0 || heads <= 0) return tfail(TLD_ERR_INVALID, "bad argument");
+    PtrDeviceGuard guard(qk);
     if (launch_attention_bwd(reinterpret_cast<const bf16*>(qk), reinterpret_cast<const bf16*>(vt), reinterpret_cast<const bf16*>(o), g,
                              reinterpret_cast<bf16*>(dqkv), batch, 256, heads, reinterpret_cast<hipStream_t>(hip_stream)))
         return tfail(TLD_ERR_INVALID, "attention backward supports 256 tokens");

@@ -199,11 +199,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16* __restrict__ 
 // dqkv [M, 3 d] bf16 out.  N must be 256.
 int launch_attention_bwd(const bf16* qk, const bf16* vt, const bf16* o, const float* g, bf16* dqkv, int batch, int ntok, int heads, hipStream_t s) {
     if (ntok != kN) return 1;
-    static bool once = false;
-    if (!once) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        once = true;
-    }
+    static PerDeviceOnce once;
+    if (once.first()) hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(batch * heads), dim3(256), kLdsBytes, s, qk, vt, o, g, dqkv, heads);
     return 0;
 }

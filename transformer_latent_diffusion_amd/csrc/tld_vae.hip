@@ -857,6 +857,7 @@ int tld_debug_conv3x3(const void* in_bf16, const void* w_bf16, float* out_f32, i
     if (!in_bf16 || !w_bf16 || !out_f32) return fail(TLD_ERR_INVALID, "null argument");
     if (cin % 64 || cin < 64) return fail(TLD_ERR_INVALID, "cin=%d must be a multiple of 64", cin);
     if (up != 0 && up != 1) return fail(TLD_ERR_INVALID, "up must be 0 or 1");
+    PtrDeviceGuard guard(in_bf16);
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     const size_t n = (size_t)B * (H >> up) * (W >> up) * cin * 2;
     if (n + kHdr >= (1ull << 32)) return fail(TLD_ERR_INVALID, "operands must be smaller than 4 GiB");

@@ -9,6 +9,7 @@ the exit edge.  CLIP and the VAE are third-party models outside the denoising pa
 """
 from __future__ import annotations
 
+import numbers
 from dataclasses import asdict, dataclass
 from typing import Any, Optional
 
@@ -175,7 +176,7 @@ class DiffusionTransformer:
         n = len(prompts)
         if n == 0:
             return []
-        seed_list = [int(seeds) + i for i in range(n)] if isinstance(seeds, int) else [int(v) for v in seeds]
+        seed_list = [int(seeds) + i for i in range(n)] if isinstance(seeds, numbers.Integral) else [int(v) for v in seeds]
         if len(seed_list) != n:
             raise ValueError(f"{len(seed_list)} seeds for {n} prompts")
         if self._text_encoder is not None:
@@ -243,10 +244,18 @@ class RequestBatcher:
         return calls
 
     def flush(self):
+        """Run every queued request; returns {ticket: image}.  Requests leave the queue as their group completes, so a failing group
+        (bad prompt, out of memory) loses nothing that was already computed: the exception carries ``partial`` = the finished images,
+        and a retry only repeats the groups that did not run."""
         out = {}
         for g, n, reqs in self.plan():
-            imgs = self.pipeline.generate_images_from_texts([p for _, p, _ in reqs], class_guidance=g,
-                                                            seeds=[s for _, _, s in reqs], n_iter=n)
+            try:
+                imgs = self.pipeline.generate_images_from_texts([p for _, p, _ in reqs], class_guidance=g,
+                                                                seeds=[s for _, _, s in reqs], n_iter=n)
+            except Exception as exc:
+                exc.partial = out
+                raise
             out.update({t: im for (t, _, _), im in zip(reqs, imgs)})
-        self._queue = []
+            done = {t for t, _, _ in reqs}
+            self._queue = [q for q in self._queue if q[0] not in done]
         return out

@@ -18,6 +18,7 @@ weights (like ``nn.Module`` construction; no checkpoint can be downloaded here).
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 import json
 import os
 from collections import OrderedDict
@@ -185,6 +186,7 @@ class AutoencoderKLDecoder:
         self._spec = vae_decoder_spec(self.config)
         self._state: "OrderedDict[str, torch.Tensor]" = OrderedDict(
             (k, torch.from_numpy(v)) for k, v in synth_vae_state_dict(self.config, init_seed).items())
+        self._weights_loaded = False     # still on the deterministic random initialisation (no checkpoint can be downloaded here)
         self.max_batch = int(max_batch)          # samples per engine call; larger batches are decoded in chunks
         self._device: Optional[torch.device] = None
         self._engine = None
@@ -233,6 +235,7 @@ class AutoencoderKLDecoder:
         if strict and missing:
             raise RuntimeError(f"missing keys in VAE state_dict: {missing[:4]}{' ...' if len(missing) > 4 else ''}")
         self._state.update(new)
+        self._weights_loaded = True
         self._drop_engine()
         return self
 
@@ -297,6 +300,10 @@ class AutoencoderKLDecoder:
         dev = z.device if z.device.type == "cuda" else (self._device or z.device)
         if dev.type != "cuda":
             raise RuntimeError("AutoencoderKLDecoder.decode needs a HIP device (tensors on 'cuda'); there is no CPU path")
+        if not self._weights_loaded:
+            self._weights_loaded = True             # (warn once per object)
+            warnings.warn("AutoencoderKLDecoder is decoding with its deterministic RANDOM initialisation: no checkpoint was loaded "
+                          "(load_state_dict / load_vae_checkpoint); the images are noise", RuntimeWarning, stacklevel=2)
         z = z.to(dev).contiguous()
         B, _, s, _ = z.shape
         self._ensure_engine(dev, s, B)
