@@ -1,12 +1,12 @@
 #!/bin/bash
-# One GPU-box call that refreshes the round-2 evidence under gpurun_out/<tag> (copied into profiles/ afterwards):
+# One GPU-box call that refreshes the evidence of a round under gpurun_out/<tag> (copied into profiles/ afterwards):
 # full GPU suite, PMC traffic (C1), bench lines C1 (with cpu_baseline) / C3 / C4 bf16 / C4 fp8, rocprofv3 kernel stats, parity report.
-T=${1:-r02}
+T=${1:-r03}; P=${2:-r03}      # tag under gpurun_out, file prefix under profiles/
 O=gpurun_out/$T
 mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests.log
 bash tools/pmc_traffic.sh $O/pmc > $O/pmc.log 2>&1; tail -6 $O/pmc.log
-cp $O/pmc/traffic.json profiles/r02_pmc_traffic.json 2>/dev/null
+cp $O/pmc/traffic.json profiles/${P}_pmc_traffic.json 2>/dev/null
 timeout 900 python bench.py --steps 5 --warmup 2 --with-vae > $O/bench_c1.json 2> $O/bench_c1.err; cut -c1-300 $O/bench_c1.json; grep -o '"with_vae".*' $O/bench_c1.json | cut -c1-400
 timeout 300 python bench.py --image-size 64 --images-per-gpu 16 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err; cut -c1-200 $O/bench_c3.json
 timeout 300 python bench.py --image-size 128 --images-per-gpu 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c4_bf16.json 2> $O/bench_c4_bf16.err; cut -c1-200 $O/bench_c4_bf16.json
@@ -29,3 +29,10 @@ cd $R
 python profiles/summarize_rocpd.py $O/prof_vae/p_results.db $O/vae_kernel_stats.csv > /dev/null 2>&1; head -8 $O/vae_kernel_stats.csv | cut -c1-150
 timeout 600 python -m pytest tests/test_gpu_vae.py -q -m gpu -s -k sdxl 2>&1 | grep -E "vae stage|passed|failed" > $O/vae_parity.txt; cut -c1-300 $O/vae_parity.txt
 rm -rf $O/prof_c1 $O/prof_c3 $O/prof_c4f $O/prof_vae $O/pmc/FETCH_SIZE $O/pmc/WRITE_SIZE
+# training step: bench line + kernel stats
+timeout 600 python tools/train_bench.py --steps 5 --warmup 2 2>/dev/null | tail -1 > $O/train_bench.json; cut -c1-300 $O/train_bench.json
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof_train -o p -- python $R/tools/train_bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/$O/prof_train.log 2>&1
+cd $R
+python profiles/summarize_rocpd.py $O/prof_train/p_results.db $O/train_kernel_stats.csv > /dev/null 2>&1; head -8 $O/train_kernel_stats.csv | cut -c1-150
+rm -rf $O/prof_train

@@ -48,7 +48,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* ht, int row, int kchunk)
 // dbg: 1 = no fragment reads after the first K-tile, 2 = no tile DMA in the loop, 4 = no MFMAs
 template <int dbg>
 __global__ __launch_bounds__(512) void gemm8p_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, bf16* __restrict__ C,
-                                                      int M, int N, int K, int store, unsigned long long* trace) {
+                                                      int M, int N, int K, int store, unsigned long long* trace, int epi_work) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -249,7 +249,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const bf16* __restrict__ A,
                         const int cl = j2 * 32 + 8 * rq + 4 * hi;
                         bf16x4 pk;
 #pragma unroll
-                        for (int e2 = 0; e2 < 4; ++e2) pk[e2] = (bf16)acc[i][j2][rq * 4 + e2];
+                        for (int e2 = 0; e2 < 4; ++e2) {
+                            float v = acc[i][j2][rq * 4 + e2];
+                            for (int wk = 0; wk < epi_work; ++wk) v = fmaf(v, 1.0001f, 0.0001f * v);   // emulated elementwise epilogue work (cf. gemm_2wg.hip)
+                            pk[e2] = (bf16)v;
+                        }
                         *reinterpret_cast<bf16x4*>(ws + l31 * 128 + ((((cl >> 3) ^ (l31 & 7)) << 4) | ((cl & 7) << 1))) = pk;
                     }
 #pragma unroll
@@ -283,7 +287,7 @@ int main(int argc, char** argv) {
     struct Shape { const char* name; int M, N, K; } shapes[] = {{"256 ", 256, 256, 256}, {"512 ", 512, 512, 512}, {"4k  ", 4096, 4096, 4096},
                                                                   {"qkv ", 32768, 2304, 768}, {"up  ", 32768, 3072, 768}, {"down", 32768, 768, 3072},
                                                                   {"8k  ", 8192, 8192, 8192}};
-    typedef void (*kern_t)(const bf16*, const bf16*, bf16*, int, int, int, int, unsigned long long*);
+    typedef void (*kern_t)(const bf16*, const bf16*, bf16*, int, int, int, int, unsigned long long*, int);
     kern_t kerns[9] = {gemm8p_kernel<0>, gemm8p_kernel<1>, gemm8p_kernel<2>, nullptr, nullptr, gemm8p_kernel<5>, nullptr, nullptr, gemm8p_kernel<8>};
     unsigned long long* dtrace = nullptr;
     hipMalloc(&dtrace, 6 * 8 * 8 * 8);
@@ -306,7 +310,7 @@ int main(int argc, char** argv) {
         hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice);
         const int ntiles = (s.M / BM) * (s.N / BN);
         const int grid = ntiles < ncu ? ntiles : ncu;
-        auto launch = [&](int store, int dbg) { hipLaunchKernelGGL(kerns[dbg], dim3(grid), dim3(512), LDS_BYTES, 0, dA, dW, dC, s.M, s.N, s.K, store, dtrace); };
+        auto launch = [&](int store, int dbg) { hipLaunchKernelGGL(kerns[dbg], dim3(grid), dim3(512), LDS_BYTES, 0, dA, dW, dC, s.M, s.N, s.K, store & 15, dtrace, store >> 4); };       // store >> 4: emulated epilogue work
         // correctness (sampled fp64 reference, asymmetric random operands) + race screen (bitwise-identical output over repeated runs)
         std::vector<uint16_t> hc(nc), hc0;
         double worst = 0.0;
@@ -334,7 +338,8 @@ int main(int argc, char** argv) {
         struct { const char* label; int store, dbg, zeros; } modes[] = {{"full (with stores)", 1, 0, 0}, {"no stores         ", 0, 0, 0}, {"no stores, zeros  ", 0, 0, 1},
                                                                         {"no stores, no DMA ", 0, 2, 0}, {"no stores, no frag", 0, 1, 0}, {"DMA + barriers only", 0, 5, 0},
                                                                         {"LDS transpose only", 2, 0, 0}, {"global stores only", 3, 0, 0}, {"nontemporal stores", 4, 0, 0},
-                                                                        {"permlane, 16-B stores", 5, 0, 0}, {"permlane, 16-B NT   ", 6, 0, 0}};
+                                                                        {"permlane, 16-B stores", 5, 0, 0}, {"permlane, 16-B NT   ", 6, 0, 0},
+                                                                        {"NT stores + 8 VALU/el", 4 + 16 * 4, 0, 0}, {"NT stores + 32 VALU/el", 4 + 16 * 16, 0, 0}};
         for (auto& md : modes) {
             if (md.zeros) { hipMemset(dA, 0, na * 2); hipMemset(dW, 0, nw * 2); }
             else { hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice); }
