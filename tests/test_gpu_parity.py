@@ -39,7 +39,9 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(_dev())
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (1000, 16, 768), (4096, 2304, 768), (2048, 768, 3072)])
+# (the last three shapes fill whole rounds of 256 x 256 tiles, which is what selects the half-tile ring K loop: even / ragged M, 2 - 8 iterations)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (1000, 16, 768), (4096, 2304, 768), (2048, 768, 3072),
+                                   (8192, 2048, 256), (8152, 2048, 384), (4096, 4096, 1024)])
 def test_gemm_bf16_vs_fp32_matmul(M, N, K):
     import ctypes as C
     from transformer_latent_diffusion_amd import _lib
