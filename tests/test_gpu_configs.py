@@ -185,6 +185,39 @@ def test_checkpoint_file_into_engine_512px(tmp_path):
     assert a.state_dict()["denoiser_trans_block.pos_embed.weight"].shape == (1024, 768)
 
 
+def test_fused_attention_cross_kernel_vs_golden(tmp_path):
+    """attn_cross_kernel (self-attention + both residual adds + cross-attention + LayerNorm-3 statistics in one kernel; opt-in with
+    TLD_FUSE_ATTN_CROSS=1 -- it measured slower than the two kernels it replaces) stays parity-green: 100 M forward and the
+    35-step trajectory of g5 in a process of its own (the switch is read once per process)."""
+    script = tmp_path / "fused.py"
+    script.write_text(f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {REPO!r}); sys.path.insert(0, {TESTS!r})
+from dataclasses import asdict
+from conftest import cfg_from_arr, load_golden, rel_rms, synth_weights
+from transformer_latent_diffusion_amd import Denoiser, DiffusionGenerator
+g = load_golden("g5_100m.npz")
+cfg = cfg_from_arr(g["cfg"]); sd = synth_weights(cfg, g["weight_seed"], g["weight_checksum"])
+dev = torch.device("cuda:0")
+m = Denoiser(**asdict(cfg)).to(dev); m.load_state_dict({{k: torch.from_numpy(np.array(v)) for k, v in sd.items()}})
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+out = m(t(g["x"]), t(g["sigma"]), t(g["label"])).cpu().numpy()
+gen = DiffusionGenerator(m, None, dev, torch.float32)
+lat = gen.generate_latents(torch.from_numpy(g["traj_labels"]), n_iter=35, num_imgs=1, class_guidance=6.0, seeds=torch.from_numpy(g["traj_seeds"]),
+                           img_size=32, sharp_f=0.0, bright_f=0.0).cpu().numpy()
+print("RESULT", rel_rms(out, g["x0"]), rel_rms(lat, g["traj_latent"]))
+""")
+    outs = {}
+    for flag in ("1", "0"):
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=dict(os.environ, TLD_FUSE_ATTN_CROSS=flag), timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        fwd, traj = (float(v) for v in r.stdout.split("RESULT")[1].split()[:2])
+        outs[flag] = (fwd, traj)
+        assert fwd <= FWD_TOL and traj <= TRAJ_TOL, (flag, fwd, traj)
+    print("fused / two-kernel (forward, trajectory):", outs)
+    assert outs["1"] != outs["0"]            # the switch really selected another kernel
+
+
 def _stress_model(g, tag, env):
     from transformer_latent_diffusion_amd import Denoiser
     cfg = cfg_from_arr(g["cfg"])

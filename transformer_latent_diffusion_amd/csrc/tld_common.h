@@ -414,6 +414,23 @@ struct CrossRowParams {
 void launch_cross_row(const CrossRowParams& p, hipStream_t s);
 bool cross_row_supports_ln3_stats(int d);
 
+// Self-attention + residual add + cross-attention + residual add + LayerNorm-3 statistics in ONE kernel (256-token grids, bf16 residual
+// stream, LayerNorm-3 folded into the up-projection): see attn_cross_kernel in tld_attn.hip.  Same tables as CrossRowParams.
+struct AttnCrossParams {
+    const bf16* qk;               // [M, 2d] q | k
+    const bf16* vt;               // [B, H, 64, N]
+    resid_t* x;                   // [M, d] residual stream, updated in place
+    const float* wq;              // [T, H, d]
+    const float* bwq;             // [T, H]
+    const float* v; int v_ld;     // [T, v_ld]
+    const int* noise_row;         // [B]
+    const int* label_row;         // [B]
+    float2* ln3_stats;            // [M] (mean, rstd) of the stored new residual rows
+    int batch, ntok, d, heads;
+};
+bool attn_cross_supported(int ntok, int d);
+void launch_attn_cross(const AttnCrossParams& p, hipStream_t s);
+
 struct TailParams {
     const resid_t* tok;           // [B*N, d]
     const float* w;               // [pd, d]

@@ -317,7 +317,21 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
 #endif
             launch_gemm(g, fold1 ? EPI_QKV_LN : EPI_QKV, s);
         }
-        {
+        // 256-token grids, bf16 stream, LayerNorm-3 folded: self-attention, both residual adds, the cross-attention sub-block and the
+        // LayerNorm-3 statistics are ONE kernel (attn_cross_kernel); `att` is never materialised.  Block 0 under CFG sharing (its
+        // attention runs on the un-doubled batch and fans out), the fp8 producers and the debug stage dumps keep the two-kernel path.
+        const bool fused_ac = attn_cross_supported(e->ntok, d) && e->fold_ln3 && !half && !e->debug && !e->fp8;
+        if (fused_ac) {
+            ProfScope ps(e, KC_ATTN, s);
+            AttnCrossParams ap{};
+            ap.qk = e->qk; ap.vt = e->vt; ap.x = e->x;
+            ap.wq = e->c_wq + (size_t)l * e->cond_cap * e->H * d;
+            ap.bwq = e->c_bwq + (size_t)l * e->cond_cap * e->H;
+            ap.v = e->c_kv + (size_t)l * e->cond_cap * 2 * d + d; ap.v_ld = 2 * d;
+            ap.noise_row = noise_row; ap.label_row = label_row; ap.ln3_stats = e->row_stats;
+            ap.batch = batch; ap.ntok = e->ntok; ap.d = d; ap.heads = e->H;
+            launch_attn_cross(ap, s);
+        } else {
             ProfScope ps(e, KC_ATTN, s);
             launch_attention(e->qk, e->vt, e->att, bl, e->ntok, e->H, s);
         }
@@ -330,7 +344,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
         // up-projection's epilogue and the pre-conv hidden never reaches HBM.  Other grids: separate kernels.
         const bool fuse_dw = e->fuse_dwconv && e->grid == 16 && e->hid % 256 == 0;
         const bool fold3 = e->fold_ln3;                 // LN3 applied in the up-projection's epilogue: cross_row writes row statistics, not xn
-        {   // x += att; x += CA(LN2 x, y); xn = LN3(x)
+        if (!fused_ac) {   // x += att; x += CA(LN2 x, y); xn = LN3(x)
             ProfScope ps(e, KC_CROSS, s);
             CrossRowParams cp{};
             cp.x = e->x; cp.att = e->att;
