@@ -343,7 +343,7 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
         hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x2, b.cr, b.x3, P + p.n3w, P + p.n3b, b.a3, b.st3, M, d);
         // x = x + MLPSepConv(LN3 x)   (:89-113,138)
         gemm_bf16(b.a3, d, b.wup, d, P + p.up_b, b.h, M, hid, d, s);
-        hipLaunchKernelGGL(dwconv_kernel, g1((size_t)M * hid / 8), blk, 0, s, b.h, b.dww_t, P + p.dw_b, b.hc, b.gl, B, G, hid, 0);
+        hipLaunchKernelGGL(dwconv_kernel, dim3(B * (hid / 64)), blk, (size_t)N * 128, s, b.h, b.dww_t, P + p.dw_b, b.hc, b.gl, B, G, hid, 0);
         gemm_bf16(b.gl, hid, b.wdown, hid, P + p.down_b, b.o, M, d, hid, s);
         bf16* xnext = i + 1 < e->L ? e->lb[i + 1].x1 : e->xfin;
         hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x3, b.o, xnext, (const float*)nullptr, (const float*)nullptr, (bf16*)nullptr, (float2*)nullptr, M, d);
@@ -362,8 +362,11 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
         using TX = std::remove_cv_t<std::remove_pointer_t<decltype(xp)>>;
         const int nb = (rows + 31) / 32;                                  // 32 rows per workgroup: >= 1024 workgroups at the training batch
         hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows, width);
-        reduce(nb, 2 * (size_t)width, 0, dgamma, width, 0);
-        reduce(nb, 2 * (size_t)width, width, dbeta, width, 0);
+        if (dbeta == dgamma + width) reduce(nb, 2 * (size_t)width, 0, dgamma, 2 * width, 0);       // (weight, bias) are neighbours in the flat vector: one launch
+        else {
+            reduce(nb, 2 * (size_t)width, 0, dgamma, width, 0);
+            reduce(nb, 2 * (size_t)width, width, dbeta, width, 0);
+        }
     };
     auto colsum = [&](auto ap, int rows, int cols, float* dst) {
         using T = std::remove_cv_t<std::remove_pointer_t<decltype(ap)>>;
@@ -383,8 +386,14 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
         int sk = 1;
         if (Nout % 256 == 0) while (sk < 8 && (M / (sk * 2)) % 128 == 0 && M / (sk * 2) >= 1024) sk *= 2;
         const int ms = M / sk;
-        hipLaunchKernelGGL((transpose_to_bf16<bf16>), dim3((Nout + 31) / 32, (M + 31) / 32), blk, 0, s, dY, Nout, e->T1, ms, M, Nout, sk);
-        hipLaunchKernelGGL((transpose_to_bf16<bf16>), dim3((Kin + 31) / 32, (M + 31) / 32), blk, 0, s, X, Kin, e->T2, ms, M, Kin, sk);
+        auto tr = [&](const bf16* src, int cols, bf16* dst) {
+            if (M % 64 == 0 && cols % 64 == 0 && ms % 64 == 0)
+                hipLaunchKernelGGL(transpose_bf16_64, dim3(cols / 64, M / 64), blk, 0, s, src, cols, dst, ms, M, cols, sk);
+            else
+                hipLaunchKernelGGL((transpose_to_bf16<bf16>), dim3((cols + 31) / 32, (M + 31) / 32), blk, 0, s, src, cols, dst, ms, M, cols, sk);
+        };
+        tr(dY, Nout, e->T1);
+        tr(X, Kin, e->T2);
         if (sk == 1) { gemm_f32(e->T1, M, e->T2, M, dW, Nout, Kin, M, s); return; }
         GemmParams g{};
         g.A = e->T1; g.lda = ms; g.W = e->T2; g.ldw = ms; g.M = sk * Nout; g.N = Kin; g.K = ms; g.c_f32 = e->splitk; g.ldc = Kin;
@@ -410,7 +419,7 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
         hipLaunchKernelGGL(gelu_bwd_kernel, g1((size_t)M * hid / 8), blk, 0, s, e->dbig, b.hc, e->dbig, (size_t)M * hid / 8);      // dhc (in place)
         hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((hid + 255) / 256, B * G), blk, 0, s, e->dbig, b.h, e->part, G, hid);
         hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 10 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B * G, hid);
-        hipLaunchKernelGGL(dwconv_kernel, g1((size_t)M * hid / 8), blk, 0, s, e->dbig, b.dww_t, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1);   // dh -> b.gl (its forward value is consumed)
+        hipLaunchKernelGGL(dwconv_kernel, dim3(B * (hid / 64)), blk, (size_t)N * 128, s, e->dbig, b.dww_t, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1);   // dh -> b.gl (its forward value is consumed)
         colsum(b.gl, M, hid, Gd + p.up_b);
         weight_grad(b.gl, hid, b.a3, d, Gd + p.up_w);
         gemm_bf16(b.gl, hid, b.wup_t, hid, e->zero_bias, e->dsmall2, M, d, hid, s);                     // da3 = dh Wup

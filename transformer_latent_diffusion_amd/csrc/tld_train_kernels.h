@@ -286,6 +286,29 @@ __global__ __launch_bounds__(256) void transpose_to_bf16(const TIN* __restrict__
         }
     }
 }
+// bf16 [R, C] -> bf16 [C, R] in 64 x 64 tiles, 16-byte global accesses both ways (R, C multiples of 64; split-K stacking as above)
+__global__ __launch_bounds__(256) void transpose_bf16_64(const bf16* __restrict__ in, int ldi, bf16* __restrict__ out, int ldo, int R, int C, int splits) {
+    __shared__ bf16 tile[64][72];                      // 144-byte pitch: 16-byte aligned rows
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = it * 256 + threadIdx.x;        // 64 rows x 8 chunks
+        const int r = idx >> 3, ch = idx & 7;
+        *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = *reinterpret_cast<const uint4*>(in + (size_t)(r0 + r) * ldi + c0 + ch * 8);
+    }
+    __syncthreads();
+    const int rs = R / splits;
+    const int sp = r0 / rs;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = it * 256 + threadIdx.x;        // 64 output rows (input columns) x 8 chunks of 8 input rows
+        const int c = idx >> 3, ch = idx & 7;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[ch * 8 + e][c];
+        *reinterpret_cast<bf16x8*>(out + ((size_t)sp * C + c0 + c) * ldo + (r0 - sp * rs) + ch * 8) = v;
+    }
+}
 __global__ void cast_f32_bf16(const float* __restrict__ in, bf16* __restrict__ out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (bf16)in[i];
@@ -451,38 +474,76 @@ __global__ void cross_bwd_kernel(const float* __restrict__ g, const bf16* __rest
 // bf16 GEMM operands), so that a thread's 8 channels are two 16-byte loads per tap.
 // forward (flip = 0): out = b + sum_taps w[c][ky][kx] in[y + ky - 1][x + kx - 1];  also gelu_out = GELU(out) when given.
 // input gradient (flip = 1, no bias): din[y][x] = sum_taps w[c][ky][kx] dout[y - ky + 1][x - kx + 1]
+// One workgroup per (sample, 64-channel slab): the slab's 16 x 16 (G x G) tokens are staged in LDS (32 KB at G = 16) with 16-byte copies,
+// then a thread (channel quad, image row) slides a rotating 3 x 3 fp32 register window along the row (the inference path's
+// dwconv_gelu_kernel recipe): every input value is read from HBM once.
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, bf16* __restrict__ out,
                                                      bf16* __restrict__ gelu_out, int B, int G, int C, int flip) {
-    // one thread: 8 consecutive channels of one position (16-byte accesses; the 9 taps of a position are L1 / L2 hits)
-    const int C8 = C >> 3;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * G * G * C8) return;
-    const int c0 = (int)(i % C8) * 8;
-    const size_t m = i / C8;
-    const int x = (int)(m % G), y = (int)((m / G) % G);
-    const size_t b = m / ((size_t)G * G);
-    float a[8];
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // [G * G tokens][64 ch] bf16
+    const int nslab = C >> 6;
+    const int b = blockIdx.x / nslab, cc = blockIdx.x - b * nslab;
+    const int ntok = G * G;
+    const bf16* src = in + (size_t)b * ntok * C + cc * 64;
+    for (int idx = threadIdx.x; idx < ntok * 8; idx += 256) {       // 8 x 16-B pieces per token
+        const int t = idx >> 3, q = idx & 7;
+        *reinterpret_cast<uint4*>(smem + t * 128 + q * 16) = *reinterpret_cast<const uint4*>(src + (size_t)t * C + q * 8);
+    }
+    const int cq = threadIdx.x & 15;
+    const int c0 = cc * 64 + cq * 4;
+    float4 wt[9];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a[e] = (bias && !flip) ? bias[c0 + e] : 0.f;
+    for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const float4*>(w + (size_t)(flip ? 8 - k : k) * C + c0);    // flipped taps = reversed order
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias && !flip) bs = *reinterpret_cast<const float4*>(bias + c0);
+    __syncthreads();
+    for (int i = threadIdx.x >> 4; i < G; i += 16) {
+        const bool up_ok = i > 0, dn_ok = i + 1 < G;
+        auto load_col = [&](int j, float4 (&col)[3]) {
+            const bool jok = j >= 0 && j < G;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int yy = flip ? y - ky + 1 : y + ky - 1, xx = flip ? x - kx + 1 : x + kx - 1;
-            if ((unsigned)yy < (unsigned)G && (unsigned)xx < (unsigned)G) {
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(in + ((b * G + yy) * G + xx) * C + c0);
-                const float4 wa = *reinterpret_cast<const float4*>(w + (size_t)(ky * 3 + kx) * C + c0);
-                const float4 wb = *reinterpret_cast<const float4*>(w + (size_t)(ky * 3 + kx) * C + c0 + 4);
-                const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a[e] = fmaf(wv[e], (float)v[e], a[e]);
+            for (int du = 0; du < 3; ++du) {
+                const bool ok = jok && (du == 1 || (du == 0 ? up_ok : dn_ok));
+                if (ok) {
+                    const bf16x4 v = *reinterpret_cast<const bf16x4*>(smem + ((i + du - 1) * G + j) * 128 + cq * 8);
+                    col[du] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+                } else {
+                    col[du] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
-        }
-    bf16x8 o, g;
+        };
+        const size_t obase = ((size_t)b * ntok + (size_t)i * G) * C + c0;
+        auto emit = [&](const float4 (&L)[3], const float4 (&Mc)[3], const float4 (&R)[3], int j) {
+            float4 a = bs;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { o[e] = (bf16)a[e]; g[e] = (bf16)gelu_exact((float)o[e]); }      // GELU of the STORED pre-activation: what the backward differentiates
-    *reinterpret_cast<bf16x8*>(out + m * C + c0) = o;
-    if (gelu_out) *reinterpret_cast<bf16x8*>(gelu_out + m * C + c0) = g;
+            for (int du = 0; du < 3; ++du) {
+                const float4 w0 = wt[du * 3 + 0], w1 = wt[du * 3 + 1], w2 = wt[du * 3 + 2];
+                a.x = fmaf(w2.x, R[du].x, fmaf(w1.x, Mc[du].x, fmaf(w0.x, L[du].x, a.x)));
+                a.y = fmaf(w2.y, R[du].y, fmaf(w1.y, Mc[du].y, fmaf(w0.y, L[du].y, a.y)));
+                a.z = fmaf(w2.z, R[du].z, fmaf(w1.z, Mc[du].z, fmaf(w0.z, L[du].z, a.z)));
+                a.w = fmaf(w2.w, R[du].w, fmaf(w1.w, Mc[du].w, fmaf(w0.w, L[du].w, a.w)));
+            }
+            bf16x4 o;
+            o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w;
+            *reinterpret_cast<bf16x4*>(out + obase + (size_t)j * C) = o;
+            if (gelu_out) {                                   // GELU of the STORED pre-activation: what the backward differentiates
+                bf16x4 g;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = (bf16)gelu_exact((float)o[e]);
+                *reinterpret_cast<bf16x4*>(gelu_out + obase + (size_t)j * C) = g;
+            }
+        };
+        float4 c0v[3], c1v[3], c2v[3];
+        load_col(-1, c0v);
+        load_col(0, c1v);
+        int j = 0;
+        for (; j + 3 <= G; j += 3) {
+            load_col(j + 1, c2v); emit(c0v, c1v, c2v, j);
+            load_col(j + 2, c0v); emit(c1v, c2v, c0v, j + 1);
+            load_col(j + 3, c1v); emit(c2v, c0v, c1v, j + 2);
+        }
+        if (j < G) { load_col(j + 1, c2v); emit(c0v, c1v, c2v, j); ++j; }
+        if (j < G) { load_col(j + 1, c0v); emit(c1v, c2v, c0v, j); }
+    }
 }
 // dhc = dg * GELU'(hc)
 __global__ void gelu_bwd_kernel(const bf16* __restrict__ dg, const bf16* __restrict__ hc, bf16* __restrict__ out, size_t n8) {
