@@ -410,6 +410,7 @@ struct CrossRowParams {
     uint8_t* xn3_s8;              //   ... and its E8M0 block scales [d/128][M][4]
     float* sa_out;                // optional debug dump of x + att  [M,d]
     int batch, ntok, d, heads;
+    int dbg;                      // attribution knob (TLD_CROSS_DBG): 1 = no logit dot products, 2 = no per-workgroup table fill either (wrong results)
 };
 void launch_cross_row(const CrossRowParams& p, hipStream_t s);
 bool cross_row_supports_ln3_stats(int d);

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
         fetch(ibase + 2 * (size_t)pr + 1, xr[1], ar[1]);
     }
 
-    {
+    if (!(p.dbg & 2)) {
         const float4* wl = reinterpret_cast<const float4*>(p.wq + (size_t)tl * H * d);
         const float4* wn = reinterpret_cast<const float4*>(p.wq + (size_t)tn * H * d);
         float4* dst = reinterpret_cast<float4*>(wd);
@@ -540,6 +540,10 @@ __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, 
         }
 
         float plab[2][NQ];
+        if (p.dbg & 1) {
+#pragma unroll
+            for (int hg = 0; hg < NQ; ++hg) { plab[0][hg] = 0.5f * rstd[0]; plab[1][hg] = 0.5f * rstd[1]; }
+        } else
 #pragma unroll
         for (int hg = 0; hg < NQ; ++hg) {
             float part[2][4];
@@ -973,7 +977,10 @@ bool cross_row_supports_ln3_stats(int d) {
     return q4 && (d == 768 || d == 512 || d == 256);
 }
 
-void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
+void launch_cross_row(const CrossRowParams& p_in, hipStream_t s) {
+    static const int dbg_env = getenv("TLD_CROSS_DBG") ? atoi(getenv("TLD_CROSS_DBG")) : 0;
+    CrossRowParams pd = p_in; pd.dbg = dbg_env;
+    const CrossRowParams& p = pd;
     // ~43 KB of LDS per workgroup -> 3 workgroups per CU.  Split each sample's row pairs into the number of
     // chunks that makes the grid ONE full resident round (768 workgroups on 256 CUs) when the batch allows,
     // else k rounds of <= ~48 rows per workgroup; a partial extra round costs as much as a full one.
