@@ -125,6 +125,9 @@ struct tld_engine {
     float *xt = nullptr, *x0_prev = nullptr, *x0_cfg = nullptr;
     int* rows_dev = nullptr;           // noise_row / label_row tables
     int64_t rows_cap = 0;
+    void* stage_host = nullptr;        // pinned staging for tld_sample's sigma / row tables
+    size_t stage_cap = 0;
+    hipEvent_t stage_ev = nullptr;     // recorded after the last copy out of stage_host
 
     // conditioning tables (sized for cond_cap token rows)
     int cond_cap = 0;
@@ -207,6 +210,19 @@ int ensure_rows_capacity(tld_engine* e, int64_t n) {
     if (n <= e->rows_cap) return TLD_OK;
     if (int rc = dev_alloc(e, &e->rows_dev, (size_t)n)) return rc;
     e->rows_cap = n;
+    return TLD_OK;
+}
+
+// Pinned host staging owned by the engine: tld_sample fills it and returns without waiting for the copies; the
+// next call waits on stage_ev (long complete by then) before overwriting.
+int stage_acquire(tld_engine* e, size_t bytes) {
+    if (!e->stage_ev) HIP_TRY(hipEventCreateWithFlags(&e->stage_ev, hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(e->stage_ev));
+    if (bytes <= e->stage_cap) return TLD_OK;
+    if (e->stage_host) { HIP_TRY(hipHostFree(e->stage_host)); e->stage_host = nullptr; e->stage_cap = 0; }
+    const size_t cap = (bytes + 4095) & ~(size_t)4095;
+    HIP_TRY(hipHostMalloc(&e->stage_host, cap, hipHostMallocDefault));
+    e->stage_cap = cap;
     return TLD_OK;
 }
 
@@ -800,9 +816,12 @@ int tld_sample(tld_engine* e, const void* x_T, const void* labels, const float* 
     if (int rc = ensure_rows_capacity(e, (int64_t)(n_levels + 1) * B2)) return rc;
 
     // ---- conditioning tables for the whole trajectory, once
-    std::vector<float> sig((size_t)n_levels);
-    for (int i = 0; i < n_levels; ++i) sig[(size_t)i] = coeffs[(size_t)i * 6 + 0];
-    HIP_TRY(hipMemcpyAsync(e->c_sigma, sig.data(), sig.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    const size_t n_rows = (size_t)(n_levels + 1) * B2;
+    if (int rc = stage_acquire(e, (size_t)n_levels * sizeof(float) + n_rows * sizeof(int))) return rc;
+    float* sig = static_cast<float*>(e->stage_host);
+    int* rows = reinterpret_cast<int*>(sig + n_levels);
+    for (int i = 0; i < n_levels; ++i) sig[i] = coeffs[(size_t)i * 6 + 0];
+    HIP_TRY(hipMemcpyAsync(e->c_sigma, sig, (size_t)n_levels * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(e->c_label, labels, (size_t)B * e->text * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemsetAsync(e->c_label + (size_t)B * e->text, 0, e->text * sizeof(float), s));   // uncond = zeros (diffusion.py:61)
     {
@@ -812,12 +831,11 @@ int tld_sample(tld_engine* e, const void* x_T, const void* labels, const float* 
     }
     if (int rc = cond_tables(e, T, s)) return rc;
     // row tables: [step][B2] noise rows, then one [B2] label-row table
-    std::vector<int> rows((size_t)(n_levels + 1) * B2);
     for (int i = 0; i < n_levels; ++i)
         for (int b = 0; b < B2; ++b) rows[(size_t)i * B2 + b] = i;
     for (int b = 0; b < B2; ++b) rows[(size_t)n_levels * B2 + b] = n_levels + (b < B ? b : B);
-    HIP_TRY(hipMemcpyAsync(e->rows_dev, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));    // host temporaries above must outlive their copies
+    HIP_TRY(hipMemcpyAsync(e->rows_dev, rows, n_rows * sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(e->stage_ev, s));     // no stream sync: the staging buffer is the engine's, guarded by this event
     const int* label_row = e->rows_dev + (size_t)n_levels * B2;
 
     const size_t tot = (size_t)B * e->img;
@@ -1034,6 +1052,8 @@ int tld_engine_destroy(tld_engine* e) {
     for (int k = 0; k < KC_COUNT; ++k)
         for (auto& ev : e->prof_ev[k]) { hipEventDestroy(ev.first); hipEventDestroy(ev.second); }
     for (void* p : e->allocs) (void)hipFree(p);
+    if (e->stage_host) (void)hipHostFree(e->stage_host);
+    if (e->stage_ev) (void)hipEventDestroy(e->stage_ev);
     delete e;
     return TLD_OK;
 }
