@@ -261,6 +261,12 @@ TLD_API int tld_train_adam_ema(tld_train* e, float* params, const float* grads, 
  * (forward output), g [M, d] fp32 (dL/dO) -> dqkv [M, 3d] bf16 (dq | dk | dv).  Device pointers. */
 TLD_API int tld_debug_attention_bwd(const void* qk, const void* vt, const void* o, const float* g, void* dqkv, int32_t batch, int32_t heads,
                                     void* hip_stream);
+/* Test / measurement hook: self-attention forward alone, softmax(q k^T / 8) v per head (head_dim 64; MHAttention.forward,
+ * tld/transformer_blocks.py:31-48).  qk [batch * ntok, 2 d] bf16 (q | k), vt [batch, heads * 64, ntok] bf16 (V transposed per head),
+ * att [batch * ntok, d] bf16 out, d = 64 heads.  iters launches back to back; *ms_per_launch (host pointer, may be NULL) receives the
+ * HIP-event average.  Device pointers. */
+TLD_API int tld_debug_attention_fwd(const void* qk, const void* vt, void* att, int32_t batch, int32_t ntok, int32_t heads, int32_t iters,
+                                    float* ms_per_launch, void* hip_stream);
 TLD_API int tld_train_destroy(tld_train* e);
 
 #ifdef __cplusplus

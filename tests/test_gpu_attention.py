@@ -1,0 +1,72 @@
+"""GPU: the self-attention kernels alone (tld_debug_attention_fwd) against an fp32 torch evaluation of the same bf16 inputs --
+softmax(q k^T / 8) v per head, head_dim 64 (MHAttention.forward, tld/transformer_blocks.py:31-48).  Covers the three kernels the
+engine dispatches to: attn_kernel (32 / 64 / 128 tokens), attn1_kernel (256 tokens, the 256 px case) and attn2_kernel (>= 512 tokens:
+two query tiles per wave, lazily advanced running max).  The "peaked" cases drive the running max through many advances (scores
+spread over hundreds of log2 units), the quantity the lazy rescaling must keep exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import _dev
+
+pytestmark = pytest.mark.gpu
+
+ATT_TOL = 5e-3          # rel-rms over the whole output (bf16 P and bf16 output rounding: measured 2.2e-3 .. 2.4e-3)
+ATT_ROW_TOL = 2e-2      # worst (token row, head) 64-vector, relative
+
+
+def _run(B, N, H, q, k, v):
+    from transformer_latent_diffusion_amd import _lib
+    d = 64 * H
+    dev = _dev()
+    qk = torch.cat([q.reshape(B * N, d), k.reshape(B * N, d)], dim=1).contiguous().to(dev)
+    vt = v.permute(0, 2, 3, 1).reshape(B, d, N).contiguous().to(dev)            # [B, H * 64, N]
+    att = torch.full((B * N, d), float("nan"), dtype=torch.bfloat16, device=dev)   # every element must be written
+    _lib.check(_lib.lib().tld_debug_attention_fwd(qk.data_ptr(), vt.data_ptr(), att.data_ptr(), B, N, H, 1, None,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "tld_debug_attention_fwd")
+    torch.cuda.synchronize()
+    return att
+
+
+def _ref(q, k, v):
+    dev = _dev()
+    qf, kf, vf = (t.float().to(dev).permute(0, 2, 1, 3) for t in (q, k, v))
+    o = torch.softmax(qf @ kf.transpose(-1, -2) / 8.0, dim=-1) @ vf               # [B, H, N, 64]
+    return o.permute(0, 2, 1, 3)                                                  # [B, N, H, 64]
+
+
+@pytest.mark.parametrize("N,B,H,scale", [(64, 3, 2, 1.0), (128, 2, 4, 1.0), (256, 3, 12, 1.0), (512, 2, 12, 1.0), (1024, 2, 12, 1.0),
+                                         (1024, 1, 4, 3.0), (2048, 1, 2, 6.0), (4096, 1, 2, 1.0)])
+def test_attention_forward_vs_fp32(N, B, H, scale):
+    g = torch.Generator().manual_seed(N + 7 * B + H)
+    q = (torch.randn(B, N, H, 64, generator=g) * scale).to(torch.bfloat16)
+    k = (torch.randn(B, N, H, 64, generator=g) * scale).to(torch.bfloat16)
+    v = torch.randn(B, N, H, 64, generator=g).to(torch.bfloat16)
+    att = _run(B, N, H, q, k, v)
+    got = att.float().reshape(B, N, H, 64)
+    ref = _ref(q, k, v)
+    assert torch.isfinite(got).all()
+    r = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    row = ((got - ref).pow(2).sum(-1).sqrt() / ref.pow(2).sum(-1).sqrt().clamp_min(1e-6)).max().item()
+    print(f"attention N={N} B={B} H={H} scale={scale}: rel-rms {r:.2e}, worst row {row:.2e}")
+    assert r <= ATT_TOL and row <= ATT_ROW_TOL, (r, row)
+    # run-to-run identical
+    assert torch.equal(att, _run(B, N, H, q, k, v))
+
+
+def test_attention_rising_scores_advance_the_running_max():
+    """Keys ordered so that every later 32-key tile carries larger scores than everything before it: the running max has to move at
+    (nearly) every tile, by far more than the lazy threshold, and the early tiles' contributions must be rescaled to (almost) nothing."""
+    N, B, H = 1024, 1, 2
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, N, H, 64, generator=g).abs().to(torch.bfloat16)              # all-positive queries ...
+    ramp = torch.linspace(0.05, 6.0, N).view(1, N, 1, 1)
+    k = (torch.rand(B, N, H, 64, generator=g) * ramp).to(torch.bfloat16)            # ... against keys growing with their index
+    v = torch.randn(B, N, H, 64, generator=g).to(torch.bfloat16)
+    got = _run(B, N, H, q, k, v).float().reshape(B, N, H, 64)
+    ref = _ref(q, k, v)
+    r = float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    print(f"rising scores: rel-rms {r:.2e}")
+    assert torch.isfinite(got).all() and r <= ATT_TOL, r

@@ -124,9 +124,13 @@ def test_fp8_c4_trajectory_vs_fp32_reference():
 @pytest.mark.parametrize("name", ["g5_100m.npz", "g7_100m_512px.npz"])
 def test_fp8_quantising_producers_equal_separate_passes(name):
     """The LayerNorm / cross-attention / tiled depthwise kernels write the MX-fp8 operands themselves; with
-    TLD_FP8_FUSED=0 the engine quantises their bf16 outputs in separate passes instead.  Same bytes, same result."""
+    TLD_FP8_FUSED=0 the engine quantises their bf16 outputs in separate passes instead.  Same bytes, same result -- for every
+    input, not one lucky one: a single bf16 value off by an ulp in one token row flips fp8 codes and shows at the output, so the
+    comparison runs over several rescaled inputs (round 3: the two LayerNorm-1 writers once differed in ~1 row of 5000 because the
+    compiler contracted their multiply-adds differently; csrc/tld_rows.hip ln_q4_stats / ln_q4_affine pin the arithmetic)."""
     import os
     g = load_golden(name)
+    scales = (1.0, 0.99, 0.97, 1.03, 0.98)
     outs = []
     for fused in ("1", "0"):
         old = os.environ.get("TLD_FP8_FUSED")
@@ -135,7 +139,9 @@ def test_fp8_quantising_producers_equal_separate_passes(name):
             cfg, m = _fp8_engine(g)
             m.reserve(8)                                 # the switch is read when the engine is created ...
             assert g["x"].shape[0] <= 8                  # ... and a larger batch would rebuild it
-            outs.append(m(_t(g["x"]), _t(g["sigma"]), _t(g["label"])).cpu().numpy())    # (forward inside the scope, so a rebuild could not flip the mode either)
+            # (forwards inside the scope, so a rebuild could not flip the mode either)
+            outs.append([m(_t(g["x"]) * sc, _t(g["sigma"]), _t(g["label"])).cpu().numpy() for sc in scales])
         finally:
             os.environ.pop("TLD_FP8_FUSED", None) if old is None else os.environ.__setitem__("TLD_FP8_FUSED", old)
-    assert np.array_equal(outs[0], outs[1])
+    for sc, a, b in zip(scales, outs[0], outs[1]):
+        assert np.array_equal(a, b), f"input scale {sc}: {int((a != b).sum())} of {a.size} outputs differ"

@@ -510,6 +510,254 @@ __global__ __launch_bounds__(NW * 64, 2) void attn1_kernel(const bf16* __restric
 }
 
 // =====================================================================================================================
+// attn2_kernel (round 3): the multi-chunk kernel for 512 / 1024 px grids (ntok >= 512), replacing attn_kernel<8, 8> there.
+// What bounded attn_kernel (151 us at C3 = 0.68 PFLOP/s, 455 us at C4): per 32-key x 32-query tile a wave spends 256 cycles of MFMA,
+// ~260 cycles of VALU (4.5 instructions per score at 2 waves/SIMD, profiles/r02_valu_issue_rates.txt) and 8 KB of LDS fragment reads
+// (= the CU's 128 B/clk for four SIMDs), and all 8 waves of the only resident workgroup walk the phases in lockstep.  Changes:
+//   * a wave owns TWO query tiles at once (64 queries): every K / V^T fragment read from LDS feeds two MFMAs -- LDS bytes per flop halve;
+//   * 4-wave workgroups (256 queries), two per CU and not synchronised with each other (74 KB of LDS each);
+//   * row max with v_max3; scale and (stale) max in one v_fma per score;
+//   * lazy rescaling: the running max is only advanced when a tile exceeds it by more than 2^kLazy (P stays <= 2^kLazy, exact in the
+//     ratio o / l); after the first tiles of a row the 32-multiply rescale of O practically never runs;
+//   * K rows land in LDS in the order [0-3, 8-11, 4-7, 12-15] of every 16 (free with the DMA's per-lane source address), which makes the
+//     keys of a lane's P fragment CONTIGUOUS: the V^T fragment is one ds_read_b128 from a plain [64][128 keys] tile, so V^T can travel
+//     by global_load_lds as well (16-byte chunk XOR swizzle by row & 15 instead of the padded pitch) -- no staging through registers;
+//   * 128-key chunks, K and V^T double-buffered with separate barriers (K of chunk c+1 is needed one tile EARLIER than its V^T, because
+//     the scores of tile i+1 are issued while tile i's softmax runs; V^T of chunk c is still in use then), counted vmcnt as in the GEMM.
+// Per tile i the wave issues S(i+1) (8 MFMAs), exp / pack of tile i, P V (8 MFMAs), row max of tile i+1.
+constexpr float kLazy = 6.0f;
+// -DTLD_A2_DBG=n: cost-attribution builds (wrong results by construction; tools/r3_attn2_attr.sh): 1 no exponentials, 2 no softmax VALU work
+// on the scores at all, 3 = 2 and no row max, 5 = 3 and no LDS fragment reads (MFMAs, DMA and barriers only)
+#ifndef TLD_A2_DBG
+#define TLD_A2_DBG 0
+#endif
+#ifndef TLD_A2_CLK
+#define TLD_A2_CLK 0
+#endif
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int N> __device__ __forceinline__ void a2_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(256, 2) void attn2_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ vt,
+                                                       bf16* __restrict__ att, int ntok, int d) {
+    constexpr int KC = 128, KB = KC * 128, VB = 64 * KC * 2, TP = 16 * 144;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int twod = 2 * d;
+    const size_t row_base = (size_t)b * ntok;
+    const int q0 = blockIdx.x * 256 + wid * 64;
+    const int nchunks = ntok / KC;
+#if TLD_A2_CLK
+    const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const bf16* qp = qk + (row_base + q0 + qt * 32 + l31) * twod + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[qt][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    }
+    const bf16* kbase0 = qk + row_base * twod + d + h * 64;
+    const bf16* vbase0 = vt + ((size_t)b * d + h * 64) * ntok;
+    auto stage_k = [&](int ch) {            // LDS row r of the chunk <- key pi(r): quads 1 and 2 of every 16 rows swapped
+        const bf16* kb = kbase0 + (size_t)ch * KC * twod;
+        char* dst = smem + (ch & 1) * KB;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int piece = wid * 4 + it;
+            const int r = piece * 8 + (lane >> 3);
+            const int key = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+            const int clog = (lane & 7) ^ ((r >> 1) & 7);
+            __builtin_amdgcn_global_load_lds((gptr_t)(kb + (size_t)key * twod + clog * 8), (lptr_t)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    auto stage_v = [&](int ch) {            // [64 features][128 keys], 16-byte chunk c of row f at chunk c ^ (f & 15)
+        const bf16* vb = vbase0 + (size_t)ch * KC;
+        char* dst = smem + 2 * KB + (ch & 1) * VB;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int piece = wid * 4 + it;
+            const int f = piece * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (f & 15);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + (size_t)f * ntok + c * 8), (lptr_t)(dst + piece * 1024), 16, 0, 0);
+        }
+    };
+    // lane parts of the fragment addresses: K row l31, chunk (2 ks + hi) ^ ((l31 >> 1) & 7);  V^T row l31 (+32 ct), chunk (2 s + hi) ^ (l31 & 15)
+    const int k_lane = l31 * 128 + ((hi ^ ((l31 >> 1) & 7)) << 4);
+    const int v_lane = l31 * 256 + ((hi ^ (l31 & 15)) << 4);
+
+    f32x16 st[2][2];            // [tile parity][query tile]
+    f32x16 o[2][2];             // [query tile][feature half]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qt][ct][r] = 0.f;
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+
+    auto scores = [&](int kofs, f32x16 (&s)[2]) {
+        bf16x8 kf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (TLD_A2_DBG == 5) kf[ks] = qf[1][ks];
+            else kf[ks] = *reinterpret_cast<const bf16x8*>(smem + ((kofs + k_lane) ^ (ks << 5)));
+        }
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+                s[qt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[qt][ks], ks ? s[qt] : zero, 0, 0, 0);
+    };
+    // row max of a fresh score tile; advances the running max (and rescales O, l) only past the lazy threshold
+    auto advance = [&](const f32x16 (&s)[2]) {
+        if constexpr (TLD_A2_DBG >= 3) return;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = fmaxf(fmaxf(s[qt][0], s[qt][1]), s[qt][2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[qt][r]), s[qt][r + 1]);
+            mx = fmaxf(mx, s[qt][15]);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * kScaleLog2e;
+            if (__builtin_amdgcn_ballot_w64(mx > m_run[qt] + kLazy) != 0) {
+                const float m_new = fmaxf(m_run[qt], mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
+                m_run[qt] = m_new;
+                l_run[qt] *= alpha;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qt][ct][r] *= alpha;
+            }
+        }
+    };
+    // P fragment (8 keys x this lane's query) of score registers [hf * 8, +8): exp2(s * scale - m) -> packed bf16; row sum in fp32.
+    // Scalar v_fma / v_add on purpose: v_pk_fma_f32, v_pk_mul_f32 and v_dot2c_f32_bf16 do NOT run beside MFMAs (they serialise with the
+    // matrix pipe and cost extra, tools/ubench/overlap2.hip: "hidden" -0.16 .. -0.31), v_fma / v_exp / v_cvt_pk / v_max3 hide 50-85 %.
+    auto probs = [&](const f32x16& s, int hf, float negm, float& l) {
+        union { bf16x8 v; unsigned u[4]; } pf;
+        if constexpr (TLD_A2_DBG >= 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pf.u[e] = __float_as_uint(s[hf * 8 + 2 * e]);
+            l = 1.f;
+            return pf.v;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float tt = __builtin_fmaf(s[hf * 8 + e], kScaleLog2e, negm);
+            const float pv = TLD_A2_DBG == 1 ? tt : __builtin_amdgcn_exp2f(tt);
+            l += pv;
+            pf.v[e] = (bf16)pv;
+        }
+        return pf.v;
+    };
+
+    stage_k(0);
+    stage_v(0);
+    stage_k(1);
+    a2_wait_vmcnt<8>();                     // Q, K(0) landed (own pieces) ...
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();           // ... everybody's
+    __builtin_amdgcn_sched_barrier(0);
+    scores(0, st[0]);
+    advance(st[0]);
+
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        const int vofs = 2 * KB + (c & 1) * VB + v_lane;
+        const bool more = c + 1 < nchunks;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t == 3 && more) {           // K(c+1) landed; every wave has read the last K fragments of chunk c: its buffer is free
+                a2_wait_vmcnt<4>();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (c + 2 < nchunks) stage_k(c + 2);
+            }
+            if (t == 0) {                   // V^T(c) landed; every wave is past the P V of chunk c-1: that buffer is free
+                if (more) a2_wait_vmcnt<4>(); else a2_wait_vmcnt<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stage_v(c + 1);
+            }
+            f32x16 (&sc)[2] = st[t & 1];
+            f32x16 (&sn)[2] = st[(t + 1) & 1];
+            // S(i+1): next tile's scores (nothing to prefetch after the very last tile).  Order inside the body is the compiler's: it
+            // interleaves these MFMAs with tile i's exponentials.  (Pinning "all fragment reads first, then VALU, then MFMAs" with
+            // sched_barriers measured 3 % slower, profiles/r03_attn2_attribution.txt.)
+            const int kofs = ((t == 3 ? c + 1 : c) & 1) * KB + ((t + 1) & 3) * 4096;
+            if (t < 3 || more) scores(kofs, sn);
+            // tile i: P and P V
+            bf16x8 pf[2][2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) pf[hf][qt] = probs(sc[qt], hf, -m_run[qt], l_run[qt]);
+                bf16x8 vf[2];
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    if constexpr (TLD_A2_DBG == 5) vf[ct] = qf[0][ct + 2 * hf];
+                    else vf[ct] = *reinterpret_cast<const bf16x8*>(smem + ((vofs + ct * 8192) ^ ((t * 2 + hf) << 5)));
+                }
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt)
+                        o[qt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ct], pf[hf][qt], o[qt][ct], 0, 0, 0);
+            }
+            if (t < 3 || more) advance(sn);
+        }
+    }
+
+    // ---- normalise, transpose through the per-wave LDS patch, whole-row stores (as attn1_kernel)
+    char* T = smem + 2 * KB + 2 * VB + wid * TP;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float lt = l_run[qt] + __shfl_xor(l_run[qt], 32, 64);
+        const float inv = 1.0f / lt;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if ((l31 >> 4) == half) {
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        bf16x4 pk;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pk[e] = (bf16)(o[qt][ct][rq * 4 + e] * inv);
+                        *reinterpret_cast<bf16x4*>(T + (l31 & 15) * 144 + ct * 64 + rq * 16 + hi * 8) = pk;
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int r = it * 8 + (lane >> 3), c16 = lane & 7;
+                const u32x4 w = *reinterpret_cast<const u32x4*>(T + r * 144 + c16 * 16);
+                __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(att + (row_base + q0 + qt * 32 + half * 16 + r) * d + h * 64 + c16 * 8));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+#if TLD_A2_CLK      // clock probe build: workgroup (0,0,0) leaves (shader-clock ticks, 100 MHz ticks) of its lifetime in att[0..15]
+    __builtin_amdgcn_s_waitcnt(0);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        uint64_t* dst = reinterpret_cast<uint64_t*>(att);
+        dst[0] = __builtin_readcyclecounter() - clk0;
+        dst[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
+#endif
+}
+
+// =====================================================================================================================
 // attn_cross_kernel (round 3): self-attention + residual add + the whole cross-attention sub-block + residual add + LayerNorm-3
 // statistics for 256-token grids in ONE kernel -- replaces attn1_kernel followed by cross_row_q4_kernel
 // (tld/transformer_blocks.py:37-44,62-72,136-137).  The 50 MB `att` tensor is never written or read back and a launch per layer goes.
@@ -890,6 +1138,14 @@ void launch_kt(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, i
     hipLaunchKernelGGL((attn_kernel<KT, NW>), grid, block, lds, s, qk, vt, att, ntok, heads * 64, nbuf);
 }
 
+void launch_attn2(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
+    constexpr int lds = 2 * 128 * 128 + 2 * 64 * 256 + 4 * 16 * 144;
+    static PerDeviceOnce attr_set;
+    if (attr_set.first())
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(attn2_kernel, dim3(ntok / 256, heads, batch), dim3(256), lds, s, qk, vt, att, ntok, heads * 64);
+}
+
 }  // namespace
 
 bool attn_cross_supported(int ntok, int d) {
@@ -929,11 +1185,13 @@ void launch_attention(const bf16* qk, const bf16* vt, bf16* att, int batch, int 
     // workgroups, two per CU (staging overlapped with compute) -- 88 us vs 60 us per layer at C1, the K/V
     // chunk is then staged twice per head and the extra L2->LDS traffic costs more than the overlap buys.
     static const bool one_wg = getenv("TLD_ATTN_8W") && atoi(getenv("TLD_ATTN_8W")) != 0;     // A/B knob: single 8-wave workgroup per CU
+    static const bool attn2_on = !(getenv("TLD_ATTN2") && atoi(getenv("TLD_ATTN2")) == 0);            // A/B knob: attn_kernel<8, 8> for >= 512 tokens
     static const bool pipe = !(getenv("TLD_ATTN_PIPE") && atoi(getenv("TLD_ATTN_PIPE")) == 0);        // A/B knob: compiler-scheduled fragment reads
     if (ntok == 256 && !one_wg) {
         if (pipe) launch_attn1<8, 4, 2, true>(qk, vt, att, batch, ntok, heads, s);
         else launch_attn1<8, 4, 2, false>(qk, vt, att, batch, ntok, heads, s);
     }
+    else if (ntok % 256 == 0 && ntok >= 512 && attn2_on) launch_attn2(qk, vt, att, batch, ntok, heads, s);
     else if (ntok % 256 == 0) launch_kt<8, 8>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 128) launch_kt<4, 4>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 64) launch_kt<2, 2>(qk, vt, att, batch, ntok, heads, s);

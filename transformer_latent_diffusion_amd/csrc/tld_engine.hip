@@ -1045,6 +1045,29 @@ int tld_engine_get_profile(tld_engine* e, int32_t kclass, double* total_ms, int6
 
 int64_t tld_engine_weight_bytes(const tld_engine* e) { return e ? e->weight_bytes : 0; }
 
+int tld_debug_attention_fwd(const void* qk, const void* vt, void* att, int32_t batch, int32_t ntok, int32_t heads, int32_t iters,
+                            float* ms_per_launch, void* hip_stream) {
+    if (!qk || !vt || !att || batch <= 0 || heads <= 0 || iters <= 0) return fail(TLD_ERR_INVALID, "bad argument");
+    if (!(ntok == 32 || ntok == 64 || ntok == 128 || (ntok > 0 && ntok % 256 == 0)))
+        return fail(TLD_ERR_INVALID, "attention supports 32, 64, 128 or a multiple of 256 tokens (got %d)", ntok);
+    PtrDeviceGuard guard(qk);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i)
+        launch_attention(static_cast<const bf16*>(qk), static_cast<const bf16*>(vt), static_cast<bf16*>(att), batch, ntok, heads, s);
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms_per_launch) *ms_per_launch = ms / (float)iters;
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
 int tld_engine_destroy(tld_engine* e) {
     if (!e) return TLD_OK;
     DeviceGuard dg(e->cfg.device_id);

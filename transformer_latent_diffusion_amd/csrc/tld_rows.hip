@@ -169,6 +169,30 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const resid_t* __re
     }
 }
 
+// LayerNorm arithmetic of the 4-features-per-lane kernels, shared by the bf16 writer and the MX-fp8 writer: the two must produce the
+// SAME bf16 values bit for bit (tests/test_gpu_fp8.py: quantising producers == separate passes).  Under HIP's -ffp-contract=fast the
+// backend decides per context which multiply-adds fuse, so identical source in two kernels is not identical arithmetic (seen: one token
+// row in ~5000 differing between the two at a LayerNorm-1); contraction is pinned here and the fused operations are spelled out.
+template <int NQ>
+__device__ __forceinline__ void ln_q4_stats(float4 (&v)[NQ], int d, float& rstd) {
+#pragma clang fp contract(off)
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+        q += __builtin_fmaf(v[j].x, v[j].x, v[j].y * v[j].y) + __builtin_fmaf(v[j].z, v[j].z, v[j].w * v[j].w);
+    }
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
+}
+__device__ __forceinline__ float ln_q4_affine(float v, float rstd, float g, float b) {
+#pragma clang fp contract(off)
+    return __builtin_fmaf(v * rstd, g, b);
+}
+
 // d % 256 == 0 form: lane l holds features {4l .. 4l+3} + 256 j, i.e. 8-byte loads of the bf16 residual and 8-byte
 // stores (the 2-feature layout above moves 4 bytes per lane and instruction)
 template <int NQ>
@@ -180,30 +204,20 @@ __global__ __launch_bounds__(256) void layernorm_bf16_q4_kernel(const resid_t* _
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     float4 v[NQ];
-    float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        v[j] = rs_load4(x + (size_t)row * d + j * 256 + 4 * lane);
-        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    }
-    const float mean = wave_sum(s) / (float)d;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
-        q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
+    for (int j = 0; j < NQ; ++j) v[j] = rs_load4(x + (size_t)row * d + j * 256 + 4 * lane);
+    float rstd;
+    ln_q4_stats<NQ>(v, d, rstd);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int n = j * 256 + 4 * lane;
         const float4 gg = *reinterpret_cast<const float4*>(g + n);
         const float4 bb = *reinterpret_cast<const float4*>(b + n);
         bf16x4 o;
-        o[0] = (bf16)(v[j].x * rstd * gg.x + bb.x);
-        o[1] = (bf16)(v[j].y * rstd * gg.y + bb.y);
-        o[2] = (bf16)(v[j].z * rstd * gg.z + bb.z);
-        o[3] = (bf16)(v[j].w * rstd * gg.w + bb.w);
+        o[0] = (bf16)ln_q4_affine(v[j].x, rstd, gg.x, bb.x);
+        o[1] = (bf16)ln_q4_affine(v[j].y, rstd, gg.y, bb.y);
+        o[2] = (bf16)ln_q4_affine(v[j].z, rstd, gg.z, bb.z);
+        o[3] = (bf16)ln_q4_affine(v[j].w, rstd, gg.w, bb.w);
         *reinterpret_cast<bf16x4*>(out + (size_t)row * d + n) = o;
     }
 }
@@ -218,28 +232,18 @@ __global__ __launch_bounds__(256) void layernorm_mx8_kernel(const resid_t* __res
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     float4 v[NQ];
-    float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        v[j] = rs_load4(x + (size_t)row * d + j * 256 + 4 * lane);
-        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    }
-    const float mean = wave_sum(s) / (float)d;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-        v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
-        q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
+    for (int j = 0; j < NQ; ++j) v[j] = rs_load4(x + (size_t)row * d + j * 256 + 4 * lane);
+    float rstd;
+    ln_q4_stats<NQ>(v, d, rstd);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
         const int n = j * 256 + 4 * lane;
         const float4 gg = *reinterpret_cast<const float4*>(g + n);
         const float4 bb = *reinterpret_cast<const float4*>(b + n);
         // (rounded through bf16 first: the operand the bf16 path would have produced is what gets quantised)
-        const float y0 = (float)(bf16)(v[j].x * rstd * gg.x + bb.x), y1 = (float)(bf16)(v[j].y * rstd * gg.y + bb.y);
-        const float y2 = (float)(bf16)(v[j].z * rstd * gg.z + bb.z), y3 = (float)(bf16)(v[j].w * rstd * gg.w + bb.w);
+        const float y0 = (float)(bf16)ln_q4_affine(v[j].x, rstd, gg.x, bb.x), y1 = (float)(bf16)ln_q4_affine(v[j].y, rstd, gg.y, bb.y);
+        const float y2 = (float)(bf16)ln_q4_affine(v[j].z, rstd, gg.z, bb.z), y3 = (float)(bf16)ln_q4_affine(v[j].w, rstd, gg.w, bb.w);
         int e8;
         const unsigned w = mx8_pack4(y0, y1, y2, y3, &e8);
         *reinterpret_cast<unsigned*>(out8 + (size_t)row * d + n) = w;
