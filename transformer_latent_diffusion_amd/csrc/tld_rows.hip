@@ -1016,9 +1016,156 @@ void launch_update(const UpdateParams& p, hipStream_t s) {
     hipLaunchKernelGGL(update_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p);
 }
 
+// Streaming form of the same computation for grids that are a multiple of 32 wide (512 / 1024 px latents; round 3): one workgroup =
+// one sample x 64 channels x a 32-column strip, walking DOWN the image.  The tiled kernel above loads an 18 x 18 halo tile, waits, computes,
+// stores -- 1.27 x the input bytes and three phases per workgroup that only other workgroups can overlap (107 us = 3.8 TB/s at C3).  Here
+//   * a fifth wave does nothing but DMA: image row r (32 tokens x 128 B = four 1-KiB pieces, + one halo token per inner strip edge) goes
+//     into slot r % NR of an LDS ring, 4 - 5 rows ahead of its first use, with a counted vmcnt of its own (the four computing waves'
+//     vmcnt sees only their stores, which nobody waits for);
+//   * the computing waves keep the 3-row window in REGISTERS (a thread owns 2 adjacent columns x 4 channels): every input row is read from
+//     LDS once and from memory once (1.0 x, + 1/32 per inner strip edge), one barrier per row;
+//   * image borders: row -1 / row g are zero registers, columns -1 / g zeroed LDS cells the DMA never writes.
+// Same halved taps, bias and half-argument GELU as the tiled kernel, same fp8 output option.
+template <bool F8OUT>
+__global__ __launch_bounds__(320, 4) void dwconv_gelu_stream_kernel(const bf16* __restrict__ in, bf16* __restrict__ out,
+                                                                 const float* __restrict__ w9c, const float* __restrict__ bias, int batch,
+                                                                 int g, int C, uint8_t* __restrict__ out8, uint8_t* __restrict__ scale8) {
+    constexpr int SW = 32, NR = 7, PF = NR - 1;
+    constexpr int RPITCH = (SW + 2) * 128;                  // one ring row: tokens j0 - 1 .. j0 + 32
+    __shared__ __attribute__((aligned(16))) char ring[NR * RPITCH];
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    const int nchunk = C / DW_CB, strips = g / SW;
+    int bid = blockIdx.x;
+    const int cc = bid % nchunk; bid /= nchunk;
+    const int sx = bid % strips;
+    const int b = bid / strips;
+    const int j0 = sx * SW;
+    const bool edge_l = sx > 0, edge_r = sx + 1 < strips;   // inner strip edges: a halo token comes from the neighbouring strip
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bf16* src = in + (size_t)b * g * g * C + cc * DW_CB;
+
+    // image columns -1 / g: zero cells (never written by the DMA)
+    if (threadIdx.x < NR * 32) {
+        const int r = threadIdx.x >> 5, w = threadIdx.x & 31;
+        if (!edge_l) *reinterpret_cast<unsigned*>(ring + r * RPITCH + w * 4) = 0u;
+        if (!edge_r) *reinterpret_cast<unsigned*>(ring + r * RPITCH + (SW + 1) * 128 + w * 4) = 0u;
+    }
+    auto stage_row = [&](int r) {       // producer wave only
+        char* dst = ring + (r % NR) * RPITCH;
+        const bf16* rp = src + ((size_t)r * g + j0) * C + (lane & 7) * 8;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc)
+            __builtin_amdgcn_global_load_lds((gp_t)(rp + (size_t)(pc * 8 + (lane >> 3)) * C), (lp_t)(dst + 128 + pc * 1024), 16, 0, 0);
+        if (lane < 8) {                 // (both halo loads are issued by every row of a strip with that edge: the count per row is uniform)
+            if (edge_l) __builtin_amdgcn_global_load_lds((gp_t)(rp - C), (lp_t)dst, 16, 0, 0);
+            if (edge_r) __builtin_amdgcn_global_load_lds((gp_t)(rp + (size_t)SW * C), (lp_t)(dst + (SW + 1) * 128), 16, 0, 0);
+        }
+    };
+    const int ndma = 4 + (edge_l ? 1 : 0) + (edge_r ? 1 : 0);
+    // before barrier B_y rows <= y + 5 have been issued and rows <= y + 1 must have landed: at most PF - 2 = 4 rows may still be in flight
+    auto wait_rows = [&]() {
+        if (ndma == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (PF - 2)) : "memory");
+        else if (ndma == 5) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (PF - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (PF - 2)) : "memory");
+    };
+    __syncthreads();                    // zero cells written before any row is read
+
+    if (wid == 4) {
+        // ---- producer: rows 0 .. PF up front, then one row per barrier
+        for (int r = 0; r <= PF && r < g; ++r) stage_row(r);
+        for (int y = 0; y < g; ++y) {
+            if (y + PF + 1 >= g) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tail: fewer rows in flight than the counted wait assumes
+            else wait_rows();
+            __builtin_amdgcn_s_barrier();                    // B_y: rows <= y + 1 are in LDS; slot of row y is free
+            if (y >= 1 && y + PF < g) stage_row(y + PF);
+        }
+        return;
+    }
+    // ---- four computing waves: thread = channel quad cq x column pair cg
+    const int cq = threadIdx.x & 15, cg = threadIdx.x >> 4;
+    const int c0 = cc * DW_CB + cq * 4;
+    f32x2 w[9][2], bs[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(w9c + (size_t)k * C + c0);
+        w[k][0] = f32x2{t.x, t.y}; w[k][1] = f32x2{t.z, t.w};
+    }
+    {
+        const float4 t = *reinterpret_cast<const float4*>(bias + c0);
+        bs[0] = f32x2{t.x, t.y}; bs[1] = f32x2{t.z, t.w};
+    }
+    // window rows: [column 2 cg - 1 .. 2 cg + 2][channel pair]
+    f32x2 R0[4][2], R1[4][2], R2[4][2];
+    auto zero_row = [&](f32x2 (&R)[4][2]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { R[k][0] = f32x2{0.f, 0.f}; R[k][1] = f32x2{0.f, 0.f}; }
+    };
+    auto read_row = [&](int r, f32x2 (&R)[4][2]) {
+        const char* rp = ring + (r % NR) * RPITCH + (2 * cg) * 128 + cq * 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>(rp + k * 128);
+            R[k][0] = f32x2{(float)v[0], (float)v[1]};
+            R[k][1] = f32x2{(float)v[2], (float)v[3]};
+        }
+    };
+    const size_t orow0 = (size_t)b * g * g + j0 + 2 * cg;
+    auto emit = [&](const f32x2 (&U)[4][2], const f32x2 (&M)[4][2], const f32x2 (&D)[4][2], int y) {
+#pragma unroll
+        for (int oc = 0; oc < 2; ++oc) {                     // output column 2 cg + oc: window columns oc .. oc + 2
+            f32x2 a[2] = {bs[0], bs[1]};
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    a[h2] = __builtin_elementwise_fma(w[0 + dx][h2], U[oc + dx][h2], a[h2]);
+                    a[h2] = __builtin_elementwise_fma(w[3 + dx][h2], M[oc + dx][h2], a[h2]);
+                    a[h2] = __builtin_elementwise_fma(w[6 + dx][h2], D[oc + dx][h2], a[h2]);
+                }
+            a[0] = gelu_erf_fast2_half(a[0]); a[1] = gelu_erf_fast2_half(a[1]);
+            bf16x4 o;
+            o[0] = (bf16)a[0][0]; o[1] = (bf16)a[0][1]; o[2] = (bf16)a[1][0]; o[3] = (bf16)a[1][1];
+            const size_t row = orow0 + (size_t)y * g + oc;
+            if constexpr (F8OUT) {
+                int e8;
+                const unsigned pk = mx8_pack4((float)o[0], (float)o[1], (float)o[2], (float)o[3], &e8);
+                *reinterpret_cast<unsigned*>(out8 + row * C + c0) = pk;
+                if ((cq & 7) == 0) scale8[mx8_scale_index(c0, row, (size_t)batch * g * g)] = (uint8_t)e8;
+            } else {
+                *reinterpret_cast<bf16x4*>(out + row * C + c0) = o;
+            }
+        }
+    };
+    zero_row(R0);                                            // image row -1
+    __builtin_amdgcn_s_barrier();                            // B_0: rows 0, 1 landed
+    read_row(0, R1);
+    // three named window rows rotate (no register copies): y, y + 1, y + 2 per trip
+    auto step = [&](f32x2 (&U)[4][2], f32x2 (&M)[4][2], f32x2 (&D)[4][2], int y) {
+        if (y > 0) __builtin_amdgcn_s_barrier();             // B_y
+        if (y + 1 < g) read_row(y + 1, D); else zero_row(D);
+        emit(U, M, D, y);
+    };
+    int y = 0;
+    for (; y + 3 <= g; y += 3) {
+        step(R0, R1, R2, y);
+        step(R1, R2, R0, y + 1);
+        step(R2, R0, R1, y + 2);
+    }
+    if (y < g) { step(R0, R1, R2, y); ++y; }
+    if (y < g) { step(R1, R2, R0, y); }
+}
+
 void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c, const float* bias, const float* w9c_half,
                         const float* bias_half, int batch, int grid, int channels, hipStream_t s, uint8_t* out8,
                         uint8_t* scale8) {
+    static const bool stream_on = !(getenv("TLD_DW_STREAM") && atoi(getenv("TLD_DW_STREAM")) == 0);      // A/B knob: the tiled kernel instead
+    if (grid > 16 && grid % 32 == 0 && stream_on) {       // row-streaming variant (ring of image rows in LDS, a DMA wave); halved tables
+        const dim3 gr((unsigned)(batch * (grid / 32) * (channels / DW_CB)));
+        if (out8) hipLaunchKernelGGL(dwconv_gelu_stream_kernel<true>, gr, dim3(320), 0, s, in, out, w9c_half, bias_half, batch, grid, channels, out8, scale8);
+        else hipLaunchKernelGGL(dwconv_gelu_stream_kernel<false>, gr, dim3(320), 0, s, in, out, w9c_half, bias_half, batch, grid, channels, out8, scale8);
+        return;
+    }
     if (grid > 16) {        // spatially tiled variant (halo in LDS); takes the halved tables
         const int tiles = (grid + 15) / 16;
         const dim3 gr((unsigned)(batch * tiles * tiles * (channels / DW_CB)));
