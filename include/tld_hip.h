@@ -267,6 +267,12 @@ TLD_API int tld_debug_attention_bwd(const void* qk, const void* vt, const void* 
  * HIP-event average.  Device pointers. */
 TLD_API int tld_debug_attention_fwd(const void* qk, const void* vt, void* att, int32_t batch, int32_t ntok, int32_t heads, int32_t iters,
                                     float* ms_per_launch, void* hip_stream);
+/* Test hook: the MLP's depthwise 3x3 convolution + GELU alone (nn.Conv2d(hid, hid, 3, padding=1, groups=hid) then nn.GELU() on the
+ * "b (h w) c -> b c h w" view, tld/transformer_blocks.py:95-103) on channels-last tokens: in / out [batch, grid * grid, channels] bf16
+ * (device), weight [channels, 9] and bias [channels] fp32 (HOST, the reference's conv.weight / conv.bias).  Runs the kernel the engine
+ * would pick for that grid (whole-image / tiled / row-streaming).  channels % 64 == 0; grid <= 16 or a multiple of 16. */
+TLD_API int tld_debug_dwconv_gelu(const void* in_bf16, const float* weight_host, const float* bias_host, void* out_bf16, int32_t batch,
+                                  int32_t grid, int32_t channels, void* hip_stream);
 TLD_API int tld_train_destroy(tld_train* e);
 
 #ifdef __cplusplus

@@ -1045,6 +1045,29 @@ int tld_engine_get_profile(tld_engine* e, int32_t kclass, double* total_ms, int6
 
 int64_t tld_engine_weight_bytes(const tld_engine* e) { return e ? e->weight_bytes : 0; }
 
+int tld_debug_dwconv_gelu(const void* in, const float* weight, const float* bias, void* out, int32_t batch, int32_t grid, int32_t channels,
+                          void* hip_stream) {
+    if (!in || !weight || !bias || !out || batch <= 0 || grid <= 0 || channels <= 0 || channels % 64) return fail(TLD_ERR_INVALID, "bad argument");
+    if (grid > 16 && grid % 16) return fail(TLD_ERR_INVALID, "grids wider than 16 tokens must be a multiple of 16 (the engine's token counts are multiples of 256)");
+    PtrDeviceGuard guard(in);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const size_t nc = (size_t)channels;
+    std::vector<float> tab(nc * 20);                       // [9][C] taps | [C] bias | the same halved
+    for (size_t c = 0; c < nc; ++c) {
+        for (int k = 0; k < 9; ++k) { tab[k * nc + c] = weight[c * 9 + k]; tab[nc * 10 + k * nc + c] = 0.5f * weight[c * 9 + k]; }
+        tab[9 * nc + c] = bias[c]; tab[nc * 19 + c] = 0.5f * bias[c];
+    }
+    float* d = nullptr;
+    HIP_TRY(hipMalloc(&d, tab.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(d, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+    launch_dwconv_gelu(static_cast<const bf16*>(in), static_cast<bf16*>(out), d, d + 9 * nc, d + 10 * nc, d + 19 * nc, batch, grid, channels, s,
+                       nullptr, nullptr);
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(d);
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
 int tld_debug_attention_fwd(const void* qk, const void* vt, void* att, int32_t batch, int32_t ntok, int32_t heads, int32_t iters,
                             float* ms_per_launch, void* hip_stream) {
     if (!qk || !vt || !att || batch <= 0 || heads <= 0 || iters <= 0) return fail(TLD_ERR_INVALID, "bad argument");
