@@ -355,13 +355,16 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
 
     // ================================================ backward ===============================================
     auto reduce = [&](int nparts, size_t stride, size_t part_off, float* dst, int n, int acc) {
-        hipLaunchKernelGGL(reduce_partials, dim3((n + 63) / 64), dim3(1024), 0, s, e->part + part_off, nparts, stride, dst, n, acc);
+        hipLaunchKernelGGL(reduce_partials, dim3((n + 15) / 16), dim3(1024), 0, s, e->part + part_off, nparts, stride, dst, n, acc);
     };
     auto ln_bwd_rows = [&](auto dyp, auto xp, const float2* st, const float* gamma, float* dx, int acc, float* dgamma, float* dbeta, int rows, int width) {
         using TDY = std::remove_cv_t<std::remove_pointer_t<decltype(dyp)>>;
         using TX = std::remove_cv_t<std::remove_pointer_t<decltype(xp)>>;
         const int nb = (rows + 31) / 32;                                  // 32 rows per workgroup: >= 1024 workgroups at the training batch
-        hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows, width);
+        if (width == 768) hipLaunchKernelGGL((ln_bwd_q4_kernel<TDY, TX, 3>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows);
+        else if (width == 512) hipLaunchKernelGGL((ln_bwd_q4_kernel<TDY, TX, 2>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows);
+        else if (width == 256) hipLaunchKernelGGL((ln_bwd_q4_kernel<TDY, TX, 1>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows);
+        else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows, width);
         if (dbeta == dgamma + width) reduce(nb, 2 * (size_t)width, 0, dgamma, 2 * width, 0);       // (weight, bias) are neighbours in the flat vector: one launch
         else {
             reduce(nb, 2 * (size_t)width, 0, dgamma, width, 0);
@@ -399,7 +402,8 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
         g.A = e->T1; g.lda = ms; g.W = e->T2; g.ldw = ms; g.M = sk * Nout; g.N = Kin; g.K = ms; g.c_f32 = e->splitk; g.ldc = Kin;
         g.w_batch_rows = Nout; g.w_batch_stride_bytes = (unsigned)((size_t)Kin * ms * 2);
         launch_gemm(g, EPI_F32, s);
-        hipLaunchKernelGGL(reduce_partials, dim3((Nout * Kin + 63) / 64), dim3(1024), 0, s, e->splitk, sk, (size_t)Nout * Kin, dW, Nout * Kin, 0);
+        if ((Nout * Kin) % 4 == 0) hipLaunchKernelGGL(sum_slices, dim3((unsigned)(((size_t)Nout * Kin / 4 + 255) / 256)), blk, 0, s, e->splitk, sk, (size_t)Nout * Kin, dW, (size_t)Nout * Kin / 4);
+        else hipLaunchKernelGGL(reduce_partials, dim3((Nout * Kin + 15) / 16), dim3(1024), 0, s, e->splitk, sk, (size_t)Nout * Kin, dW, Nout * Kin, 0);
     };
 
     // out_proj: gx = dout Wout;  dWout = dout^T x_final;  dbout
@@ -417,8 +421,13 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
         weight_grad(e->gxb, d, b.gl, hid, Gd + p.down_w);
         gemm_bf16(e->gxb, d, b.wdown_t, d, e->zero_bias, e->dbig, M, hid, d, s);                         // dg = go Wdown
         hipLaunchKernelGGL(gelu_bwd_kernel, g1((size_t)M * hid / 8), blk, 0, s, e->dbig, b.hc, e->dbig, (size_t)M * hid / 8);      // dhc (in place)
-        hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((hid + 255) / 256, B * G), blk, 0, s, e->dbig, b.h, e->part, G, hid);
-        hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 10 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B * G, hid);
+        if (G <= 16 && N >= 160 && hid % 64 == 0) {      // both images of a (sample, 64-channel chunk) in LDS: each operand is read once (N >= 160: room for the reduction buffer)
+            hipLaunchKernelGGL(dwconv_wgrad_img_kernel, dim3(B * (hid / 64)), blk, (size_t)2 * N * 128, s, e->dbig, b.h, e->part, G, hid);
+            hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 10 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B, hid);
+        } else {
+            hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((hid + 255) / 256, B * G), blk, 0, s, e->dbig, b.h, e->part, G, hid);
+            hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 10 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B * G, hid);
+        }
         hipLaunchKernelGGL(dwconv_kernel, dim3(B * (hid / 64)), blk, (size_t)N * 128, s, e->dbig, b.dww_t, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1);   // dh -> b.gl (its forward value is consumed)
         colsum(b.gl, M, hid, Gd + p.up_b);
         weight_grad(b.gl, hid, b.a3, d, Gd + p.up_w);

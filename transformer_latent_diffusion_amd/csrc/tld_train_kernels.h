@@ -16,6 +16,11 @@ constexpr float kEps = 1e-5f;
 
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16* p) { return (float)*p; }
+__device__ __forceinline__ f32x4 ldf4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ldf4(const bf16* p) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
 
 // exact-erf GELU and its derivative (nn.GELU default; tld/denoiser.py:108, tld/transformer_blocks.py:103)
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -153,22 +158,86 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         part[((size_t)blockIdx.x * 2 + 1) * d + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
     }
 }
-// out[c] (+)= sum_i part[i * stride + c]   (fixed order: bit-reproducible).  64 columns x 16 part-lanes per workgroup: lane l sums the parts
-// l, l + 16, ... and an LDS tree finishes -- the outputs are few (a weight's size), the parts up to thousands.
+// d % 256 == 0 form of the same kernel: lane l owns features {4 l .. 4 l + 3} + 256 j, i.e. 8- / 16-byte accesses instead of 2 / 4
+// (115 -> see profiles: the 2-byte form ran at 2.3 TB/s).  Same arithmetic per element; the row means are summed in a different lane order.
+template <typename TDY, typename TX, int NQ>
+__global__ __launch_bounds__(256) void ln_bwd_q4_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float2* __restrict__ stats,
+                                                        const float* __restrict__ gamma, float* __restrict__ dx, int accumulate,
+                                                        float* __restrict__ part, int rows_per_block, int M) {
+    constexpr int d = NQ * 256;
+    __shared__ float red[4][2][d];
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x4 dg[NQ], db[NQ], gm[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) { dg[j] = f32x4{0.f, 0.f, 0.f, 0.f}; db[j] = dg[j]; gm[j] = ldf4(gamma + j * 256 + 4 * lane); }
+    const int r0 = blockIdx.x * rows_per_block;
+    for (int rr = wid; rr < rows_per_block; rr += 4) {
+        const int row = r0 + rr;
+        if (row >= M) break;
+        const float2 st = stats[row];
+        f32x4 g[NQ], xh[NQ];
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const size_t o = (size_t)row * d + j * 256 + 4 * lane;
+            const f32x4 dyv = ldf4(dy + o);
+            xh[j] = (ldf4(x + o) - st.x) * st.y;
+            g[j] = dyv * gm[j];
+            s1 += g[j]; s2 = __builtin_elementwise_fma(g[j], xh[j], s2);
+            dg[j] = __builtin_elementwise_fma(dyv, xh[j], dg[j]); db[j] += dyv;
+        }
+        const float m1 = wave_sum((s1[0] + s1[1]) + (s1[2] + s1[3])) / (float)d, m2 = wave_sum((s2[0] + s2[1]) + (s2[2] + s2[3])) / (float)d;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            f32x4 o = (g[j] - m1 - xh[j] * m2) * st.y;
+            f32x4* px = reinterpret_cast<f32x4*>(dx + (size_t)row * d + j * 256 + 4 * lane);
+            if (accumulate) o += *px;
+            *px = o;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        *reinterpret_cast<f32x4*>(&red[wid][0][j * 256 + 4 * lane]) = dg[j];
+        *reinterpret_cast<f32x4*>(&red[wid][1][j * 256 + 4 * lane]) = db[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        part[((size_t)blockIdx.x * 2 + 0) * d + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
+        part[((size_t)blockIdx.x * 2 + 1) * d + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+    }
+}
+// out[c] (+)= sum_i part[i * stride + c]   (fixed order: bit-reproducible).  16 columns x 64 part-lanes per workgroup: lane l sums the parts
+// l, l + 64, ... and an LDS tree finishes -- the outputs are few (a weight's size), the parts up to thousands.
 __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ part, int nparts, size_t stride, float* __restrict__ out, int n, int accumulate) {
-    __shared__ float red[16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    // 16 columns x 64 part-lanes per workgroup (round 3; was 64 x 16): the outputs are a weight's size (a few thousand), so column blocks of
+    // 64 left 24 workgroups walking 1024 parts in 64 dependent steps each -- 30 us per call, 118 calls per step
+    __shared__ float red[64][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tx;
     float a = 0.f;
-    if (c < n) for (int i = ty; i < nparts; i += 16) a += part[(size_t)i * stride + c];
+    if (c < n) for (int i = ty; i < nparts; i += 64) a += part[(size_t)i * stride + c];
     red[ty][tx] = a;
     __syncthreads();
-    if (ty == 0 && c < n) {
+    if (ty < 4) {                                  // four part-lane groups of 16, then the last four: fixed order
         float t = 0.f;
 #pragma unroll
-        for (int l = 0; l < 16; ++l) t += red[l][tx];
+        for (int l = 0; l < 16; ++l) t += red[ty * 16 + l][tx];
+        red[ty * 16][tx] = t;
+    }
+    __syncthreads();
+    if (ty == 0 && c < n) {
+        const float t = (red[0][tx] + red[16][tx]) + (red[32][tx] + red[48][tx]);
         out[c] = accumulate ? out[c] + t : t;
     }
+}
+// out[c] = sum_{i < nparts} part[i * stride + c] for FEW parts and MANY outputs (the split-K slices of a weight gradient): a thread per four
+// outputs, slices added in order.  n % 4 == 0, stride % 4 == 0.
+__global__ void sum_slices(const float* __restrict__ part, int nparts, size_t stride, float* __restrict__ out, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 a = reinterpret_cast<const f32x4*>(part)[i];
+    for (int k = 1; k < nparts; ++k) a += reinterpret_cast<const f32x4*>(part + (size_t)k * stride)[i];
+    reinterpret_cast<f32x4*>(out)[i] = a;
 }
 // [C][9] -> [9][C]  (tap-major copy of a depthwise weight)
 __global__ void dw_tapmajor_kernel(const float* __restrict__ w, float* __restrict__ out, int C) {
@@ -588,6 +657,82 @@ __global__ void dwconv_wgrad_kernel(const bf16* __restrict__ dout, const bf16* _
     }
 #pragma unroll
     for (int k = 0; k < 10; ++k) part[(by * 10 + k) * C + c] = acc[k];
+}
+// The same partials per SAMPLE for grids up to 16 x 16 (the training config): one workgroup = one sample x 64 channels with both images
+// (`in` and `dout`, G x G tokens x 128 B each) brought into LDS by global->LDS DMA, so each operand is read from memory once (the kernel
+// above reads `in` three times with 2-byte accesses and writes / re-reads 250 MB of per-row partials).  A thread owns a channel quad and one
+// image row, slides a 3 x 3 register window of `in` along x, accumulates its 9 taps + bias in fp32, and the 16 rows are then added in a fixed
+// order through LDS: part[b][10][C].
+__global__ __launch_bounds__(256) void dwconv_wgrad_img_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ in, float* __restrict__ part,
+                                                               int G, int C) {
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    typedef __attribute__((address_space(3))) void* lp_t;
+    const int N = G * G, nchunk = C >> 6;
+    const int b = blockIdx.x / nchunk, cc = blockIdx.x - b * nchunk;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* Iin = wsm;                               // [N][64 ch] bf16
+    char* Idy = wsm + (size_t)N * 128;
+    const int pieces = (N + 7) >> 3;               // 8 tokens x 128 B per DMA instruction
+    for (int pc = wid; pc < 2 * pieces; pc += 4) {
+        const bool second = pc >= pieces;
+        const int q = second ? pc - pieces : pc;
+        int t = q * 8 + (lane >> 3);
+        t = t < N ? t : N - 1;
+        const bf16* sp = (second ? dout : in) + ((size_t)b * N + t) * C + cc * 64 + (lane & 7) * 8;
+        __builtin_amdgcn_global_load_lds((gp_t)sp, (lp_t)((second ? Idy : Iin) + q * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int cq = threadIdx.x & 15, y = threadIdx.x >> 4;      // 16 channel quads x up to 16 image rows
+    f32x2 acc[10][2];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { acc[k][0] = f32x2{0.f, 0.f}; acc[k][1] = f32x2{0.f, 0.f}; }
+    if (y < G) {
+        auto ld = [&](const char* img, int yy, int xx, f32x2 (&v)[2]) {
+            if ((unsigned)yy < (unsigned)G && (unsigned)xx < (unsigned)G) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(img + (size_t)(yy * G + xx) * 128 + cq * 8);
+                v[0] = f32x2{(float)t[0], (float)t[1]}; v[1] = f32x2{(float)t[2], (float)t[3]};
+            } else { v[0] = f32x2{0.f, 0.f}; v[1] = f32x2{0.f, 0.f}; }
+        };
+        f32x2 w0[3][2], w1[3][2], w2[3][2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { w0[r][0] = f32x2{0.f, 0.f}; w0[r][1] = f32x2{0.f, 0.f}; ld(Iin, y + r - 1, 0, w1[r]); }
+        for (int x = 0; x < G; ++x) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) ld(Iin, y + r - 1, x + 1, w2[r]);
+            f32x2 gv[2];
+            ld(Idy, y, x, gv);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                acc[9][h2] += gv[h2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    acc[r * 3 + 0][h2] = __builtin_elementwise_fma(gv[h2], w0[r][h2], acc[r * 3 + 0][h2]);
+                    acc[r * 3 + 1][h2] = __builtin_elementwise_fma(gv[h2], w1[r][h2], acc[r * 3 + 1][h2]);
+                    acc[r * 3 + 2][h2] = __builtin_elementwise_fma(gv[h2], w2[r][h2], acc[r * 3 + 2][h2]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) { w0[r][h2] = w1[r][h2]; w1[r][h2] = w2[r][h2]; }
+        }
+    }
+    __syncthreads();                               // images consumed: their LDS becomes the [16 rows][10][64 ch] reduction buffer (40 KB <= 2 N 128 B for N = 256)
+    float* red = reinterpret_cast<float*>(wsm);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        float* dst = red + ((size_t)y * 10 + k) * 64 + cq * 4;
+        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[k][0][0], acc[k][0][1], acc[k][1][0], acc[k][1][1]};
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 640; i += 256) {                 // (tap k, channel c) of this chunk; rows added in order
+        float t = 0.f;
+        for (int r = 0; r < 16; ++r) t += red[(size_t)r * 640 + i];
+        const int k = i >> 6, c = i & 63;
+        part[((size_t)b * 10 + k) * C + cc * 64 + c] = t;
+    }
 }
 // dw [C, 9] / db [C] from part[nparts][10][C]  (64 (tap, channel) outputs x 16 part-lanes per workgroup, fixed order)
 __global__ __launch_bounds__(1024) void dwconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nparts, int C) {
