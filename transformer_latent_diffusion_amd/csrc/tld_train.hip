@@ -199,6 +199,7 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
         size_t need = nchunk * 2 * (size_t)wide;                              // LN / colsum partials
         if (((M + 31) / 32) * 2 * (size_t)d > need) need = ((M + 31) / 32) * 2 * (size_t)d;   // LayerNorm-backward partials (32-row workgroups)
         if (B * e->G * 10 * (size_t)hid > need) need = B * e->G * 10 * (size_t)hid;          // depthwise weight-gradient partials (per sample and image row)
+        if (((M + 63) / 64) * (size_t)wide > need) need = ((M + 63) / 64) * (size_t)wide;     // column-sum partials (64-row chunks)
         DALLOC(e->splitk, 8 * (size_t)wide * d);
         if (nchunk * (size_t)pd * d > need) need = nchunk * (size_t)pd * d;    // tall weight-gradient partials
         e->part_floats = need;
@@ -373,6 +374,12 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
     };
     auto colsum = [&](auto ap, int rows, int cols, float* dst) {
         using T = std::remove_cv_t<std::remove_pointer_t<decltype(ap)>>;
+        if (cols % 4 == 0 && rows >= 4096) {        // four columns per thread, 64-row chunks (the chunk count feeds the 64 part-lanes of the reduction)
+            const int nb = (rows + 63) / 64;
+            hipLaunchKernelGGL((colsum4_partial<T>), dim3((cols / 4 + 255) / 256, nb), blk, 0, s, ap, rows, cols, 64, e->part);
+            reduce(nb, (size_t)cols, 0, dst, cols, 0);
+            return;
+        }
         const int nb = (rows + 255) / 256;
         hipLaunchKernelGGL((colsum_partial<T>), dim3((cols + 255) / 256, nb), blk, 0, s, ap, rows, cols, 256, e->part);
         reduce(nb, (size_t)cols, 0, dst, cols, 0);

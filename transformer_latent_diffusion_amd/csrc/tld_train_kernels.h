@@ -41,17 +41,39 @@ __global__ __launch_bounds__(256) void tiled_f32_kernel(const float* __restrict_
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        for (int t = threadIdx.x; t < 1024; t += 256) {
+    // the next K-step's operands are fetched into registers before this step's FMAs (round 3: every step used to expose a global-memory
+    // round trip between two barriers -- 91 us for products of 0.6 GFLOP); same FMA chains in k order
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = threadIdx.x + u * 256;
             // the faster-varying index of a load follows the operand's unit stride so that both layouts read coalesced
             int ii, kk;
             if (sak == 1) { kk = t & 31; ii = t >> 5; } else { ii = t & 31; kk = t >> 5; }
-            sa[kk][ii] = (i0 + ii < I && k0 + kk < K) ? A[(long)(i0 + ii) * sai + (long)(k0 + kk) * sak] : 0.f;
+            ra[u] = (i0 + ii < I && k0 + kk < K) ? A[(long)(i0 + ii) * sai + (long)(k0 + kk) * sak] : 0.f;
             int jj, k2;
             if (sbk == 1) { k2 = t & 31; jj = t >> 5; } else { jj = t & 31; k2 = t >> 5; }
-            sb[k2][jj] = (j0 + jj < J && k0 + k2 < K) ? B[(long)(j0 + jj) * sbj + (long)(k0 + k2) * sbk] : 0.f;
+            rb[u] = (j0 + jj < J && k0 + k2 < K) ? B[(long)(j0 + jj) * sbj + (long)(k0 + k2) * sbk] : 0.f;
         }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = threadIdx.x + u * 256;
+            int ii, kk;
+            if (sak == 1) { kk = t & 31; ii = t >> 5; } else { ii = t & 31; kk = t >> 5; }
+            sa[kk][ii] = ra[u];
+            int jj, k2;
+            if (sbk == 1) { k2 = t & 31; jj = t >> 5; } else { jj = t & 31; k2 = t >> 5; }
+            sb[k2][jj] = rb[u];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        stash();
         __syncthreads();
+        if (k0 + 32 < K) fetch(k0 + 32);
 #pragma unroll
         for (int kk = 0; kk < 32; ++kk) {
             const float a0 = sa[kk][ty * 2], a1 = sa[kk][ty * 2 + 1], b0 = sb[kk][tx * 2], b1 = sb[kk][tx * 2 + 1];
@@ -255,6 +277,16 @@ __global__ void colsum_partial(const T* __restrict__ a, int M, int C, int rows_p
     float s = 0.f;
     for (int r = r0; r < r1; ++r) s += ldf(a + (size_t)r * C + c);
     part[(size_t)blockIdx.y * C + c] = s;
+}
+// C % 4 == 0 form: a thread owns four adjacent columns (8- / 16-byte loads; the 2-byte form above ran at 2 TB/s on the MLP bias gradients)
+template <typename T>
+__global__ void colsum4_partial(const T* __restrict__ a, int M, int C, int rows_per_chunk, float* __restrict__ part) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r) s += ldf4(a + (size_t)r * C + c);
+    *reinterpret_cast<f32x4*>(part + (size_t)blockIdx.y * C + c) = s;
 }
 
 // LayerNorm backward over NARROW rows (width <= 64: the patch LayerNorm, tld/denoiser.py:42): one thread per row;
@@ -474,63 +506,89 @@ __global__ void patches_kernel(const float* __restrict__ x, float* __restrict__ 
 // ---- cross-attention over the two conditioning tokens (tld/transformer_blocks.py:62-72) -----------------------------------------------
 // One workgroup per (sample, head), one thread per token.  kv [B, 2, 2d] fp32 = (k | v) of tokens (noise, label).
 // forward:  p0 = softmax([q.k0, q.k1] / 8)[0];  out = p0 v0 + (1 - p0) v1
-__global__ void cross_fwd_kernel(const bf16* __restrict__ q, const float* __restrict__ kv, bf16* __restrict__ out, float* __restrict__ p0_out,
-                                 int N, int d) {
+// (round 3: eight lanes per token, 16-byte accesses -- a thread per token with 2-byte loads / stores ran at 157 / 177 us per launch)
+__global__ __launch_bounds__(256) void cross_fwd_kernel(const bf16* __restrict__ q, const float* __restrict__ kv, bf16* __restrict__ out,
+                                                        float* __restrict__ p0_out, int N, int d) {
     const int H = d >> 6, b = blockIdx.x / H, h = blockIdx.x % H;
-    __shared__ float sk[2][64], sv[2][64];
-    if (threadIdx.x < 128) {
-        const int t = threadIdx.x >> 6, i = threadIdx.x & 63;
-        sk[t][i] = kv[((size_t)b * 2 + t) * 2 * d + h * 64 + i];
-        sv[t][i] = kv[((size_t)b * 2 + t) * 2 * d + d + h * 64 + i];
+    const int sub = threadIdx.x & 7, tl = threadIdx.x >> 3;      // feature octet of the head, token slot (32 tokens per pass)
+    float k0[8], k1[8], v0[8], v1[8];
+    {
+        const float* kb0 = kv + ((size_t)b * 2 + 0) * 2 * d + h * 64 + sub * 8;
+        const float* kb1 = kv + ((size_t)b * 2 + 1) * 2 * d + h * 64 + sub * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { k0[e] = kb0[e]; k1[e] = kb1[e]; v0[e] = kb0[d + e]; v1[e] = kb1[d + e]; }
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < N; t += blockDim.x) {
+    for (int t = tl; t < N; t += 32) {
         const size_t row = (size_t)b * N + t;
-        const bf16* qr = q + row * d + h * 64;
+        const bf16x8 q8 = *reinterpret_cast<const bf16x8*>(q + row * d + h * 64 + sub * 8);
         float s0 = 0.f, s1 = 0.f;
-        for (int i = 0; i < 64; ++i) { const float qi = (float)qr[i]; s0 = fmaf(qi, sk[0][i], s0); s1 = fmaf(qi, sk[1][i], s1); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float qi = (float)q8[e]; s0 = fmaf(qi, k0[e], s0); s1 = fmaf(qi, k1[e], s1); }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { s0 += __shfl_xor(s0, m, 64); s1 += __shfl_xor(s1, m, 64); }
         const float p0 = 1.0f / (1.0f + __expf((s1 - s0) * 0.125f));
-        p0_out[row * H + h] = p0;
-        bf16* o = out + row * d + h * 64;
-        for (int i = 0; i < 64; ++i) o[i] = (bf16)(p0 * sv[0][i] + (1.0f - p0) * sv[1][i]);
+        if (sub == 0) p0_out[row * H + h] = p0;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(p0 * v0[e] + (1.0f - p0) * v1[e]);
+        *reinterpret_cast<bf16x8*>(out + row * d + h * 64 + sub * 8) = o;
     }
 }
 // backward:  g = dL/dout (fp32 [M, d]).  dq -> bf16 [M, d];  dkv[b, t, :] (fp32, written: one workgroup owns a (sample, head) slice)
-__global__ void cross_bwd_kernel(const float* __restrict__ g, const bf16* __restrict__ q, const float* __restrict__ kv, const float* __restrict__ p0_in,
-                                 bf16* __restrict__ dq, float* __restrict__ dkv, int N, int d) {
+__global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict__ g, const bf16* __restrict__ q, const float* __restrict__ kv,
+                                                        const float* __restrict__ p0_in, bf16* __restrict__ dq, float* __restrict__ dkv, int N, int d) {
     const int H = d >> 6, b = blockIdx.x / H, h = blockIdx.x % H;
-    __shared__ float sk[2][64], sv[2][64];
     extern __shared__ float sm[];                 // [N] ds0, [N] p0
+    __shared__ float red[4][3][64];
     float* ds = sm; float* pp = sm + N;
-    if (threadIdx.x < 128) {
-        const int t = threadIdx.x >> 6, i = threadIdx.x & 63;
-        sk[t][i] = kv[((size_t)b * 2 + t) * 2 * d + h * 64 + i];
-        sv[t][i] = kv[((size_t)b * 2 + t) * 2 * d + d + h * 64 + i];
+    const int sub = threadIdx.x & 7, tl = threadIdx.x >> 3;
+    float kd[8], v0[8], v1[8];
+    {
+        const float* kb0 = kv + ((size_t)b * 2 + 0) * 2 * d + h * 64 + sub * 8;
+        const float* kb1 = kv + ((size_t)b * 2 + 1) * 2 * d + h * 64 + sub * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kd[e] = kb0[e] - kb1[e]; v0[e] = kb0[d + e]; v1[e] = kb1[d + e]; }
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < N; t += blockDim.x) {
+    for (int t = tl; t < N; t += 32) {
         const size_t row = (size_t)b * N + t;
-        const float* gr = g + row * d + h * 64;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(g + row * d + h * 64 + sub * 8);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(g + row * d + h * 64 + sub * 8 + 4);
         float d0 = 0.f, d1 = 0.f;
-        for (int i = 0; i < 64; ++i) { d0 = fmaf(gr[i], sv[0][i], d0); d1 = fmaf(gr[i], sv[1][i], d1); }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            d0 = fmaf(ga[e], v0[e], d0); d1 = fmaf(ga[e], v1[e], d1);
+            d0 = fmaf(gb[e], v0[4 + e], d0); d1 = fmaf(gb[e], v1[4 + e], d1);
+        }
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) { d0 += __shfl_xor(d0, m, 64); d1 += __shfl_xor(d1, m, 64); }
         const float p0 = p0_in[row * H + h];
-        const float s0 = p0 * (1.0f - p0) * (d0 - d1);                     // dL/ds0 = -dL/ds1  (scores before the 1/8 scale: x 1/8 below)
-        ds[t] = s0 * 0.125f; pp[t] = p0;
-        bf16* o = dq + row * d + h * 64;
-        for (int i = 0; i < 64; ++i) o[i] = (bf16)(s0 * 0.125f * (sk[0][i] - sk[1][i]));
+        const float s0 = p0 * (1.0f - p0) * (d0 - d1) * 0.125f;            // dL/ds0 = -dL/ds1, with the 1/8 score scale
+        if (sub == 0) { ds[t] = s0; pp[t] = p0; }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(s0 * kd[e]);
+        *reinterpret_cast<bf16x8*>(dq + row * d + h * 64 + sub * 8) = o;
     }
     __syncthreads();
-    // reductions over the sample's tokens: thread i < 64 owns feature i of this head
-    if (threadIdx.x < 64) {
-        const int i = threadIdx.x;
+    // reductions over the sample's tokens: feature i of this head, tokens split over the four waves (added in a fixed order afterwards)
+    {
+        const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
         float dk0 = 0.f, dv0 = 0.f, dv1 = 0.f;
-        for (int t = 0; t < N; ++t) {
+        for (int t = part; t < N; t += 4) {
             const size_t row = (size_t)b * N + t;
             const float gi = g[row * d + h * 64 + i];
             dk0 = fmaf(ds[t], (float)q[row * d + h * 64 + i], dk0);
             dv0 = fmaf(pp[t], gi, dv0);
             dv1 = fmaf(1.0f - pp[t], gi, dv1);
         }
+        red[part][0][i] = dk0; red[part][1][i] = dv0; red[part][2][i] = dv1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        const float dk0 = (red[0][0][i] + red[1][0][i]) + (red[2][0][i] + red[3][0][i]);
+        const float dv0 = (red[0][1][i] + red[1][1][i]) + (red[2][1][i] + red[3][1][i]);
+        const float dv1 = (red[0][2][i] + red[1][2][i]) + (red[2][2][i] + red[3][2][i]);
         float* o0 = dkv + ((size_t)b * 2 + 0) * 2 * d;
         float* o1 = dkv + ((size_t)b * 2 + 1) * 2 * d;
         o0[h * 64 + i] = dk0; o1[h * 64 + i] = -dk0;
