@@ -1321,7 +1321,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
                             : ((E) == EPI_UP_DWCONV && G::UPDW_LDS > G::LDS_BYTES ? G::UPDW_LDS       \
                             : ((E) == EPI_UP_DWCONV2 ? G::UPDW2_LDS                                   \
                             : ((E) == EPI_QKV_LN ? G::QKVLN_LDS                                        \
-                            : ((E) == EPI_BIAS_BF16 ? G::PLAINLN_LDS : G::LDS_BYTES))));              \
+                            : ((E) == EPI_BIAS_BF16 && BN != 384 ? G::PLAINLN_LDS : G::LDS_BYTES))));  /* (384-wide: 160 KB of stages, no LayerNorm-3 fold) */ \
         constexpr bool ring_ok = TLD_KLOOP_RING && BN == 256 && !(F8) && !(CV);                       \
         if constexpr (ring_ok) {                                                                      \
             if (use_ring) TLD_L256P_LAUNCH(E, F8, CV, true); else TLD_L256P_LAUNCH(E, F8, CV, false); \
@@ -1351,7 +1351,9 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
         } else if constexpr (BN == 192) {
             if (epilogue == EPI_BIAS_RESID) TLD_L256P_(EPI_BIAS_RESID, true);
         }
-    } else if constexpr (BN == 192 || BN == 384) {
+    } else if constexpr (BN == 384) {       // residual add (the down projection) and, for the training step's N = 768 linears, bias -> bf16
+        if (epilogue == EPI_BIAS_BF16) TLD_L256P(EPI_BIAS_BF16); else TLD_L256P(EPI_BIAS_RESID);
+    } else if constexpr (BN == 192) {
         TLD_L256P(EPI_BIAS_RESID);
     } else {
         switch (epilogue) {
@@ -1379,7 +1381,9 @@ namespace {
 int choose_bn(long M, long N, int epilogue) {
     const long ntm = (M + 255) / 256;
     const long blocks256 = ntm * ((N + 255) / 256);
-    const bool narrow = (N % 256 != 0) || (blocks256 % 256 != 0 && blocks256 < 3 * 256);
+    // (a last round that is at least 85 % full counts as whole: 252 tiles on 256 CUs are not a reason to halve the tile)
+    const long rounds256 = (blocks256 + 255) / 256;
+    const bool narrow = (N % 256 != 0) || (blocks256 * 100 < rounds256 * 256 * 85 && blocks256 < 3 * 256);
     static const char* force = getenv("TLD_GEMM_BN");             // experiment knob
     int bn = narrow ? 128 : 256;
     if (narrow && epilogue == EPI_BIAS_RESID && N % 192 == 0 && (ntm * (N / 192)) % 256 == 0) bn = 192;
@@ -1392,7 +1396,10 @@ int choose_bn(long M, long N, int epilogue) {
     if (force) bn = atoi(force);
     if (epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
     if (bn == 192 && (epilogue != EPI_BIAS_RESID || N % 192)) bn = 128;
-    if (bn == 384 && (epilogue != EPI_BIAS_RESID || N % 384)) bn = 128;
+    // N = 768 with the plain bias epilogue (the training step's five per layer): one round of 256 x 384 tiles at the training batch instead of
+    // three rounds of 256 x 128 (0.71 -> 1.0 PFLOP/s)
+    if (wide && !force && epilogue == EPI_BIAS_BF16 && N % 384 == 0 && N < 1536 && (ntm * (N / 384)) % 256 == 0) bn = 384;      // (callers with a LayerNorm-3 fold have N = 4 d >= 1536)
+    if (bn == 384 && ((epilogue != EPI_BIAS_RESID && epilogue != EPI_BIAS_BF16) || N % 384)) bn = 128;
     if (bn != 256 && bn != 192 && bn != 384) bn = 128;
     return bn;
 }

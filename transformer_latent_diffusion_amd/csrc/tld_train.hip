@@ -100,6 +100,7 @@ struct tld_train {
     float* splitk;                       // split-K partials of the weight-gradient GEMMs [8][max(hid, 3d)][d]
     float* part;                         // reduction partials
     size_t part_floats = 0;
+    size_t tr_rows = 0, splitk_floats = 0;      // capacity of the transposed split-K operands (rows) and of the slice buffer
     bool weights_fresh = false;
 };
 
@@ -193,14 +194,15 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
         DALLOC(e->dpn, M * pd); DALLOC(e->dp16, M * pd); DALLOC(e->est1, M); DALLOC(e->est2, M); DALLOC(e->xfin, M * d);
         DALLOC(e->dout, M * pd); DALLOC(e->row_loss, M); DALLOC(e->io, 4);
         const size_t wide = hid > 3 * d ? hid : 3 * d;
-        DALLOC(e->gx, M * d); DALLOC(e->gxb, M * d); DALLOC(e->T1, M * wide); DALLOC(e->T2, M * wide); DALLOC(e->dbig, M * hid);
+        DALLOC(e->gx, M * d); DALLOC(e->gxb, M * d); e->tr_rows = M + 4096; DALLOC(e->T1, e->tr_rows * wide); DALLOC(e->T2, e->tr_rows * wide); DALLOC(e->dbig, M * hid);
         DALLOC(e->dsmall, M * 3 * d); DALLOC(e->dsmall2, M * d); DALLOC(e->scr, (size_t)pd * d + 64);
         const size_t nchunk = (M + 255) / 256;
         size_t need = nchunk * 2 * (size_t)wide;                              // LN / colsum partials
         if (((M + 31) / 32) * 2 * (size_t)d > need) need = ((M + 31) / 32) * 2 * (size_t)d;   // LayerNorm-backward partials (32-row workgroups)
         if (B * e->G * 10 * (size_t)hid > need) need = B * e->G * 10 * (size_t)hid;          // depthwise weight-gradient partials (per sample and image row)
         if (((M + 63) / 64) * (size_t)wide > need) need = ((M + 63) / 64) * (size_t)wide;     // column-sum partials (64-row chunks)
-        DALLOC(e->splitk, 8 * (size_t)wide * d);
+        e->splitk_floats = 8 * (size_t)wide * d;
+        DALLOC(e->splitk, e->splitk_floats);
         if (nchunk * (size_t)pd * d > need) need = nchunk * (size_t)pd * d;    // tall weight-gradient partials
         e->part_floats = need;
         DALLOC(e->part, need);
@@ -395,16 +397,33 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
     auto weight_grad = [&](const bf16* dY, int Nout, const bf16* X, int Kin, float* dW) {
         int sk = 1;
         if (Nout % 256 == 0) while (sk < 8 && (M / (sk * 2)) % 128 == 0 && M / (sk * 2) >= 1024) sk *= 2;
-        const int ms = M / sk;
+        int ms = M / sk;
+        // Round 3: any split count, runs padded to a multiple of 128 rows (zero rows contribute nothing).  With 256 x 256 tiles the launch has
+        // sk (Nout / 256) (Kin / 256) workgroups; pick the sk whose last round is fullest (e.g. 7 x 12 x 3 = 252 of 256 CUs for the
+        // up-projection weight instead of 8 x 12 x 6 = 576 128-wide tiles = 2.25 rounds), discounted by the padding.
+        if (Nout % 256 == 0 && Kin % 256 == 0 && M % 64 == 0 && M >= 4096) {
+            const int ncu = device_cu_count();
+            const long per = (long)(Nout / 256) * (Kin / 256);
+            double best = 0.0; int bsk = 0, bms = 0;
+            for (int c = 2; c <= 32; ++c) {
+                const int mp = ((M + c - 1) / c + 127) / 128 * 128;
+                if (mp < 1024 || (long)(c - 1) * mp >= M) continue;                                     // runs too short / last run empty
+                if ((size_t)c * Nout * Kin > e->splitk_floats || (size_t)c * mp > e->tr_rows) continue;   // workspace
+                const long tiles = per * c, rounds = (tiles + ncu - 1) / ncu;
+                const double eff = (double)tiles / (double)(rounds * ncu) * ((double)M / ((double)c * mp));
+                if (eff > best + 1e-9) { best = eff; bsk = c; bms = mp; }
+            }
+            if (bsk) { sk = bsk; ms = bms; }
+        }
         auto tr = [&](const bf16* src, int cols, bf16* dst) {
             if (M % 64 == 0 && cols % 64 == 0 && ms % 64 == 0)
-                hipLaunchKernelGGL(transpose_bf16_64, dim3(cols / 64, M / 64), blk, 0, s, src, cols, dst, ms, M, cols, sk);
+                hipLaunchKernelGGL(transpose_bf16_64, dim3(cols / 64, sk * ms / 64), blk, 0, s, src, cols, dst, ms, M, cols, sk);
             else
                 hipLaunchKernelGGL((transpose_to_bf16<bf16>), dim3((cols + 31) / 32, (M + 31) / 32), blk, 0, s, src, cols, dst, ms, M, cols, sk);
         };
         tr(dY, Nout, e->T1);
         tr(X, Kin, e->T2);
-        if (sk == 1) { gemm_f32(e->T1, M, e->T2, M, dW, Nout, Kin, M, s); return; }
+        if (sk == 1) { gemm_f32(e->T1, M, e->T2, M, dW, Nout, Kin, M, s); return; }      // (ms == M here)
         GemmParams g{};
         g.A = e->T1; g.lda = ms; g.W = e->T2; g.ldw = ms; g.M = sk * Nout; g.N = Kin; g.K = ms; g.c_f32 = e->splitk; g.ldc = Kin;
         g.w_batch_rows = Nout; g.w_batch_stride_bytes = (unsigned)((size_t)Kin * ms * 2);

@@ -389,17 +389,20 @@ __global__ __launch_bounds__(256) void transpose_to_bf16(const TIN* __restrict__
 }
 // bf16 [R, C] -> bf16 [C, R] in 64 x 64 tiles, 16-byte global accesses both ways (R, C multiples of 64; split-K stacking as above)
 __global__ __launch_bounds__(256) void transpose_bf16_64(const bf16* __restrict__ in, int ldi, bf16* __restrict__ out, int ldo, int R, int C, int splits) {
+    // the runs are ldo rows long; splits * ldo may exceed R (runs padded to a multiple of 128 so that any split count fits): the grid covers
+    // the padded rows and the blocks past R write zeros
     __shared__ bf16 tile[64][72];                      // 144-byte pitch: 16-byte aligned rows
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int idx = it * 256 + threadIdx.x;        // 64 rows x 8 chunks
         const int r = idx >> 3, ch = idx & 7;
-        *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = *reinterpret_cast<const uint4*>(in + (size_t)(r0 + r) * ldi + c0 + ch * 8);
+        *reinterpret_cast<uint4*>(&tile[r][ch * 8]) = r0 < R ? *reinterpret_cast<const uint4*>(in + (size_t)(r0 + r) * ldi + c0 + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
-    const int rs = R / splits;
+    const int rs = ldo;
     const int sp = r0 / rs;
+    (void)splits;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int idx = it * 256 + threadIdx.x;        // 64 output rows (input columns) x 8 chunks of 8 input rows
