@@ -120,7 +120,7 @@ struct G256P : G256<BN> {
 template <int BN, int EPI, bool F8 = false, bool CONV = false, bool RING = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks) {
     using G = G256P<BN>;
-    static_assert(!RING || (BN == 256 && !F8 && !CONV && TLD_KLOOP_STAGGER), "the half-tile ring exists for plain bf16 256 x 256 tiles");
+    static_assert(!RING || (BN == 256 && !F8 && TLD_KLOOP_STAGGER), "the half-tile ring exists for bf16 256 x 256 tiles");
     using frag_t = std::conditional_t<F8, i32x8, bf16x8>;
     constexpr int ESZ = F8 ? 1 : 2;                                     // operand bytes per element
     constexpr int SC_OFF = G::LDS_BYTES;                                // F8: [stage][A scales 1 KiB | W scales 1 KiB] behind the stages
@@ -311,7 +311,61 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     // B_h the W rows {wn * 64 + h * 32 + [0, 32)}: quadrant (qa, qb) of every wave's 128 x 64 output reads exactly A_qa and B_qb.
     constexpr int HT = 16384;
     unsigned rvA[RING ? 4 : 1], rvB[RING ? 4 : 1];            // [half * 2 + piece]: per-lane source byte offsets
+    // RING + CONV: output pixel (y << 16 | x) and first source pixel of the sample for the four A rows this lane brings in per K-tile; the
+    // A offsets are rebuilt from them whenever the stream moves on to the next of the nine taps (ring_conv_tap)
+    unsigned rcpix[RING && CONV ? 4 : 1], rcbase[RING && CONV ? 4 : 1];
+    auto ring_conv_tap = [&](int tap) {
+        if constexpr (RING && CONV) {
+            const int ky = tap / 3;
+            const int dy = ky - 1, dx = tap - ky * 3 - 1;
+            const int ws_ = p.cv_w >> p.cv_up;
+            unsigned full = ~0u;
+            asm volatile("" : "+s"(full));
+            int ln = (int)__builtin_amdgcn_mbcnt_hi(full, __builtin_amdgcn_mbcnt_lo(full, 0u));
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int r = (wid * 2 + q2) * 8 + (ln >> 3);
+                    const unsigned c16 = (unsigned)(((ln & 7) ^ ((r >> 1) & 7)) * 16);
+                    const int yy = (int)(rcpix[h * 2 + q2] >> 16) + dy, xx = (int)(rcpix[h * 2 + q2] & 0xffffu) + dx;
+                    const bool inb = (unsigned)yy < (unsigned)p.cv_h && (unsigned)xx < (unsigned)p.cv_w;
+                    const unsigned sp = rcbase[h * 2 + q2] + (unsigned)((yy >> p.cv_up) * ws_ + (xx >> p.cv_up));
+                    unsigned v = inb ? p.cv_data_off + sp * (unsigned)(p.cv_cin * 2) + c16 : c16;     // outside: the zero page
+                    asm volatile("" : "+v"(v));
+                    rvA[h * 2 + q2] = v;
+                }
+        }
+    };
     auto ring_offsets = [&](int tm0, int tn0) {
+        if constexpr (RING && CONV) {
+            unsigned full = ~0u;
+            asm volatile("" : "+s"(full));
+            int ln = (int)__builtin_amdgcn_mbcnt_hi(full, __builtin_amdgcn_mbcnt_lo(full, 0u));
+            asm volatile("" : "+v"(ln));
+            const unsigned hw = (unsigned)(p.cv_h * p.cv_w);
+            const unsigned shw = (unsigned)((p.cv_h >> p.cv_up) * (p.cv_w >> p.cv_up));
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int r = (wid * 2 + q2) * 8 + (ln >> 3);
+                    const unsigned c16 = (unsigned)(((ln & 7) ^ ((r >> 1) & 7)) * 16);
+                    int ga = tm0 + (r >> 6) * 128 + h * 64 + (r & 63);
+                    ga = ga < p.M ? ga : p.M - 1;
+                    const unsigned bb = (unsigned)ga / hw, rem = (unsigned)ga - bb * hw;
+                    const unsigned y = rem / (unsigned)p.cv_w, x = rem - y * (unsigned)p.cv_w;
+                    rcpix[h * 2 + q2] = (y << 16) | x;
+                    rcbase[h * 2 + q2] = bb * shw;
+                    int gb = tn0 + (r >> 5) * 64 + h * 32 + (r & 31);
+                    gb = gb < p.N ? gb : p.N - 1;
+                    unsigned vb = __umul24((unsigned)gb, (unsigned)(p.ldw * 2)) + c16;
+                    asm volatile("" : "+v"(vb));
+                    rvB[h * 2 + q2] = vb;
+                }
+            ring_conv_tap(0);
+        } else
         if constexpr (RING) {
             int ln = lane;
             asm volatile("" : "+v"(ln));
@@ -343,7 +397,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             constexpr int i = decltype(ic)::value;
             constexpr bool isA = (i & 1) != 0;
             constexpr int half = i >> 1;
-            const char* base = reinterpret_cast<const char*>(isA ? (const void*)p.A : (const void*)p.W) + (size_t)tk * (G::BK * 2);
+            size_t koff = (size_t)tk * (G::BK * 2);
+            if constexpr (CONV && isA) {        // K-tile tk = (tap, 64-channel block): the A side addresses a 128-byte channel slice of a shifted pixel
+                const int ckpt = p.cv_cin >> 6, tap = tk / ckpt, cb = tk - tap * ckpt;
+                if (i == 1 && cb == 0 && tk > 0) ring_conv_tap(tap);      // A0 is the first A element of a K-tile: new tap, new offsets (tap 0: ring_offsets)
+                koff = (size_t)cb * (G::BK * 2);
+            }
+            const char* base = reinterpret_cast<const char*>(isA ? (const void*)p.A : (const void*)p.W) + koff;
             asm volatile("" : "+s"(base));         // one SGPR pair + a 32-bit lane offset per piece (no 64-bit vector address arithmetic)
             char* dst = smem + slot * HT + wid * 2048;
             unsigned o0 = isA ? rvA[half * 2] : rvB[half * 2], o1 = isA ? rvA[half * 2 + 1] : rvB[half * 2 + 1];
@@ -1301,7 +1361,8 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     // half-tile ring K loop (256 x 256 tiles, bf16, no conv): an iteration is two K-tiles, so K must be a multiple of 128
     static const bool ring_env = !(getenv("TLD_GEMM_RING") && atoi(getenv("TLD_GEMM_RING")) == 0);        // A/B knob
     static const int ring_mask = getenv("TLD_GEMM_RING_MASK") ? atoi(getenv("TLD_GEMM_RING_MASK")) : 0x7f;   // A/B knob: bit e = epilogue e may use the ring
-    const bool use_ring = ring_env && ((ring_mask >> epilogue) & 1) && p.K >= 128 && p.K % 128 == 0;
+    const bool use_ring = p.conv ? (ring_env && ((ring_mask >> epilogue) & 1) && (9 * (p.cv_cin >> 6)) % 2 == 0 && !(getenv("TLD_CONV_RING") && atoi(getenv("TLD_CONV_RING")) == 0))
+                                 : (ring_env && ((ring_mask >> epilogue) & 1) && p.K >= 128 && p.K % 128 == 0);      // (conv: K = 9 cv_cin, an even number of 64-wide K-tiles)
     (void)use_ring;
     GemmParams pg = p;
     if ((epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
@@ -1322,7 +1383,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
                             : ((E) == EPI_UP_DWCONV2 ? G::UPDW2_LDS                                   \
                             : ((E) == EPI_QKV_LN ? G::QKVLN_LDS                                        \
                             : ((E) == EPI_BIAS_BF16 && BN != 384 ? G::PLAINLN_LDS : G::LDS_BYTES))));  /* (384-wide: 160 KB of stages, no LayerNorm-3 fold) */ \
-        constexpr bool ring_ok = TLD_KLOOP_RING && BN == 256 && !(F8) && !(CV);                       \
+        constexpr bool ring_ok = TLD_KLOOP_RING && BN == 256 && !(F8);                                \
         if constexpr (ring_ok) {                                                                      \
             if (use_ring) TLD_L256P_LAUNCH(E, F8, CV, true); else TLD_L256P_LAUNCH(E, F8, CV, false); \
         } else {                                                                                      \
