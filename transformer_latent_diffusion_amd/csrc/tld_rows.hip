@@ -441,13 +441,17 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
 // bf16 streams instead of 4-byte ones; LayerNorm measured 20 -> 18 us from that alone).  The features of group j
 // in lane l belong to head 4j + (l >> 4), so the four logit sums of a head quartet are finished with two
 // v_permlane32_swap, one v_permlane16_swap and one 16-lane DPP reduction: row q of the wave ends with head 4j+q.
-template <int NQ>
+// BW (round 3): the folded query-difference table is kept in LDS as bf16 and the centred rows are packed to bf16 for the 12 logit dot
+// products, which then run on v_dot2_f32_bf16 (fp32 accumulate) -- half the LDS bytes per row (reading the fp32 table, 18 KB per row, was what
+// the logits cost: 11 of the kernel's 45 us) and half the instructions.  No MFMA runs in this kernel, so the dot instructions cost nothing
+// extra here.  Same operand precision as every GEMM of the path.  OFF by default (TLD_CROSS_BF16=1 selects it): see launch_cross_row.
+template <int NQ, bool BW>
 __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, int chunks_per_sample) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int d = NQ * 256, H = NQ * 4;
     constexpr float inv_d = 1.0f / (float)d;
-    float* wd = reinterpret_cast<float*>(smem);          // [H][d]  wq_label - wq_noise (gamma folded)
-    float* vn = wd + H * d;                              // [d]     value row of the noise token
+    float* wd = reinterpret_cast<float*>(smem);          // [H][d]  wq_label - wq_noise (gamma folded); BW: bf16 [H][d] in the first half
+    float* vn = wd + (BW ? H * d / 2 : H * d);           // [d]     value row of the noise token
     float* vdiff = vn + d;                               // [d]     v_label - v_noise
     float* bw = vdiff + d;                               // [H]     beta contribution to the logit diff
 
@@ -485,7 +489,13 @@ __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, 
         float4* dst = reinterpret_cast<float4*>(wd);
         for (int i = threadIdx.x; i < H * d / 4; i += 256) {
             const float4 a = wl[i], c = wn[i];
-            dst[i] = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
+            if constexpr (BW) {
+                bf16x4 o;
+                o[0] = (bf16)(a.x - c.x); o[1] = (bf16)(a.y - c.y); o[2] = (bf16)(a.z - c.z); o[3] = (bf16)(a.w - c.w);
+                reinterpret_cast<bf16x4*>(wd)[i] = o;
+            } else {
+                dst[i] = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
+            }
         }
     }
     for (int i = threadIdx.x; i < d; i += 256) {
@@ -551,6 +561,30 @@ __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, 
 #pragma unroll
         for (int hg = 0; hg < NQ; ++hg) {
             float part[2][4];
+            if constexpr (BW) {
+                union pk4 { bf16x4 v; bf16x2 h[2]; };
+                pk4 cp[2][NQ];                        // (re-packed per head quartet: keeping them live across the loop costs registers)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) { cp[u][j].v[0] = (bf16)c[u][j][0]; cp[u][j].v[1] = (bf16)c[u][j][1]; cp[u][j].v[2] = (bf16)c[u][j][2]; cp[u][j].v[3] = (bf16)c[u][j][3]; }
+#pragma unroll
+                for (int hh = 0; hh < 4; ++hh) {
+                    float acc[2] = {0.f, 0.f};
+                    const bf16* w0 = reinterpret_cast<const bf16*>(wd) + (4 * hg + hh) * d + 4 * lane;
+#pragma unroll
+                    for (int j = 0; j < NQ; ++j) {
+                        pk4 a;
+                        a.v = *reinterpret_cast<const bf16x4*>(w0 + j * 256);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            acc[u] = __builtin_amdgcn_fdot2_f32_bf16(cp[u][j].h[0], a.h[0], acc[u], false);
+                            acc[u] = __builtin_amdgcn_fdot2_f32_bf16(cp[u][j].h[1], a.h[1], acc[u], false);
+                        }
+                    }
+                    part[0][hh] = acc[0]; part[1][hh] = acc[1];
+                }
+            } else
 #pragma unroll
             for (int hh = 0; hh < 4; ++hh) {
                 f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -998,9 +1032,19 @@ void launch_cross_row(const CrossRowParams& p_in, hipStream_t s) {
     const int lds = (p.heads * p.d + 2 * p.d + p.heads) * (int)sizeof(float);
     dim3 grid((unsigned)(p.batch * cps));
     static const bool q4 = !(getenv("TLD_CROSS_Q4") && atoi(getenv("TLD_CROSS_Q4")) == 0);      // A/B knob
-    if (q4 && p.d == 768) { hipLaunchKernelGGL(cross_row_q4_kernel<3>, grid, dim3(256), lds, s, p, (int)cps); return; }
-    if (q4 && p.d == 512) { hipLaunchKernelGGL(cross_row_q4_kernel<2>, grid, dim3(256), lds, s, p, (int)cps); return; }
-    if (q4 && p.d == 256) { hipLaunchKernelGGL(cross_row_q4_kernel<1>, grid, dim3(256), lds, s, p, (int)cps); return; }
+    // bf16 logit table + v_dot2: measured 46.8 -> 44.4 us per launch (+0.5 % end to end) for a forward rel-rms of 6.5e-3 instead of 6.3e-3 (g5):
+    // not worth the precision; opt-in (profiles/r03_cross_row_bf16_logits.txt)
+    static const bool bw = getenv("TLD_CROSS_BF16") && atoi(getenv("TLD_CROSS_BF16")) != 0;
+    if (q4 && bw && (p.d == 768 || p.d == 512 || p.d == 256)) {
+        const int lds16 = (p.heads * p.d / 2 + 2 * p.d + p.heads) * (int)sizeof(float);
+        if (p.d == 768) hipLaunchKernelGGL((cross_row_q4_kernel<3, true>), grid, dim3(256), lds16, s, p, (int)cps);
+        else if (p.d == 512) hipLaunchKernelGGL((cross_row_q4_kernel<2, true>), grid, dim3(256), lds16, s, p, (int)cps);
+        else hipLaunchKernelGGL((cross_row_q4_kernel<1, true>), grid, dim3(256), lds16, s, p, (int)cps);
+        return;
+    }
+    if (q4 && p.d == 768) { hipLaunchKernelGGL((cross_row_q4_kernel<3, false>), grid, dim3(256), lds, s, p, (int)cps); return; }
+    if (q4 && p.d == 512) { hipLaunchKernelGGL((cross_row_q4_kernel<2, false>), grid, dim3(256), lds, s, p, (int)cps); return; }
+    if (q4 && p.d == 256) { hipLaunchKernelGGL((cross_row_q4_kernel<1, false>), grid, dim3(256), lds, s, p, (int)cps); return; }
     TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(cross_row_kernel<NJ>, grid, dim3(256), lds, s, p, (int)cps));
 }
 
