@@ -41,7 +41,10 @@ def _t(a):
 
 # (the last three shapes fill whole rounds of 256 x 256 tiles, which is what selects the half-tile ring K loop: even / ragged M, 2 - 8 iterations)
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (1000, 16, 768), (4096, 2304, 768), (2048, 768, 3072),
-                                   (8192, 2048, 256), (8152, 2048, 384), (4096, 4096, 1024)])
+                                   (8192, 2048, 256), (8152, 2048, 384), (4096, 4096, 1024),
+                                   # more tiles than one round with a partly filled last round: its tiles are split by rows between two workgroups
+                                   # (48 x 8 = 384 tiles: 16 of every XCD's 48; 36 x 9 = 324: 8 or 9 of 40 / 41; ragged M)
+                                   (12288, 2048, 512), (9216, 2304, 768), (12200, 2048, 256)])
 def test_gemm_bf16_vs_fp32_matmul(M, N, K):
     import ctypes as C
     from transformer_latent_diffusion_amd import _lib
@@ -57,6 +60,20 @@ def test_gemm_bf16_vs_fp32_matmul(M, N, K):
     err = (c - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err <= 2e-5 * scale * np.sqrt(K / 64) + 1e-5, (err, scale)
+    if M * N >= 256 * 256 * 300:
+        # the row-split tail of the last round accumulates every element exactly as a whole tile does: bitwise equal to the unsplit run
+        import os, subprocess, sys
+        np.save("/tmp/_tld_gemm_tail.npy", c.cpu().numpy())
+        code = ("import sys, numpy as np, torch, ctypes as C; from transformer_latent_diffusion_amd import _lib\n"
+                f"M, N, K = {M}, {N}, {K}\n"
+                "g = torch.Generator().manual_seed(M + N + K)\n"
+                "a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda(); w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).cuda()\n"
+                "c = torch.empty(M, N, device='cuda', dtype=torch.float32)\n"
+                "_lib.check(_lib.lib().tld_debug_gemm_bf16(a.data_ptr(), w.data_ptr(), c.data_ptr(), M, N, K, C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'gemm')\n"
+                "torch.cuda.synchronize(); assert np.array_equal(c.cpu().numpy(), np.load('/tmp/_tld_gemm_tail.npy')), 'half-tile tail changed the result'\n")
+        env = dict(os.environ, TLD_GEMM_HALFTAIL="0")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
 
 
 def test_g1_stages_tiny32():

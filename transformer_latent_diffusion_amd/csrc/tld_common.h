@@ -335,6 +335,7 @@ struct GemmParams {
     int gn_groups, gn_cpg, gn_hw;
     unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0
+    int half_tail;                // ring K loop: split the tiles of a partly filled last round by ROWS between two workgroups (set by the launcher)
     int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop
     int dbg_epi;                  // experiment knob, builds with -DTLD_DBG_EPI only (TLD_EPI_DBG bit mask, see tld_gemm.hip)
 };

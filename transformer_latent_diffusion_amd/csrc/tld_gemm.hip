@@ -154,14 +154,29 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     const int q = ntiles >> 3, rr = ntiles & 7;
     const int xbase = xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
     const int xcount = G2 > 1 ? (r1 - r0) * gcols : q + (xcd < rr ? 1 : 0);
-    const int my_tiles = lidx < xcount ? (xcount - lidx + per_xcd_blocks - 1) / per_xcd_blocks : 0;
+    int my_tiles = lidx < xcount ? (xcount - lidx + per_xcd_blocks - 1) / per_xcd_blocks : 0;
+    // Half-tile tail (RING): when the XCD's last round has R left-over tiles for P workgroups and 2 R <= P, each left-over tile is computed
+    // by TWO workgroups as their last item -- workgroup j the rows {wm 128 + [0, 64)} (quadrant row qa = 0 of every wave), workgroup R + j
+    // the rows {wm 128 + 64 + [0, 64)} -- so every workgroup's time is q tiles + about 0.6 instead of q + 1 for some and q for the rest
+    // (QKV at C1: 1152 tiles = 4.5 rounds).  No data moves between the two; each output element is accumulated exactly as in the whole
+    // tile, so results stay bitwise independent of how the tiles were cut.  The half-tile's K loop keeps every phase, barrier and DMA of the
+    // full one and only skips the MFMAs and A-fragment reads of the other quadrant row.
+    constexpr bool HT_OK = RING && !CONV && (EPI == EPI_F32 || EPI == EPI_QKV || EPI == EPI_QKV_LN || EPI == EPI_BIAS_BF16);
+    const int ht_q = xcount / per_xcd_blocks, ht_R = xcount - ht_q * per_xcd_blocks;
+    const bool ht = HT_OK && p.half_tail && G2 == 1 && ht_R > 0 && 2 * ht_R <= per_xcd_blocks;
+    const int ht_qa = lidx >= ht_R ? 1 : 0;
+    if (ht) my_tiles = ht_q + (lidx < 2 * ht_R ? 1 : 0);
+    auto item_tile = [&](int i) {                   // position of work item i in the XCD's run of tiles
+        if (ht && i == ht_q) return ht_q * per_xcd_blocks + (lidx < ht_R ? lidx : lidx - ht_R);
+        return lidx + i * per_xcd_blocks;
+    };
     auto tile_coords = [&](int i, int& m0, int& n0) {
         // Row-major over tiles (n fastest), and XCD x owns a contiguous run of it: the ~32 workgroups of an XCD then
         // work on a few tile-rows x ALL tile-columns at a time, so an A tile is fetched into the XCD's L2 once and
         // serves every column while it is hot, and the W tiles are re-used by every round.  (The earlier order --
         // super-rows of 8 tile-rows, m fastest -- revisited each A super-row once per group of 4 columns, a full
         // round apart: PMC L2-miss traffic 381 MB vs 204 MB algorithmic on the QKV GEMM; this order: 134 -> 111 us.)
-        const int t = lidx + i * per_xcd_blocks;
+        const int t = item_tile(i);
         if (G2 > 1) {
             const int tm = t / gcols;
             m0 = (r0 + tm) * G::BM;
@@ -431,6 +446,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         bool v_tile = false;
         if constexpr (IS_QKV) v_tile = n0 >= 2 * p.d;
 
+        const bool hmode = ht && it == ht_q;          // this item is one row half (ht_qa) of a left-over tile
         f32x16 acc[G::TM][G::TN];
 #pragma unroll
         for (int i = 0; i < G::TM; ++i)
@@ -725,18 +741,22 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks) fb0[ks] = rd(rb[ks], 0);
                         __builtin_amdgcn_sched_barrier(0);
+                        if (!(hmode && ht_qa == 1)) {
 #pragma unroll
                         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                             for (int ks = 0; ks < 4; ++ks) fa[ii][ks] = rd(ra[ks], HT + ii * 4096);
+                        }
                     } else if constexpr (q == 1) {
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks) fb1[ks] = rd(rb[ks], 2 * HT);
                     } else if constexpr (q == 2) {
+                        if (!(hmode && ht_qa == 0)) {
 #pragma unroll
                         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                             for (int ks = 0; ks < 4; ++ks) fa[ii][ks] = rd(ra[ks], 3 * HT + ii * 4096);
+                        }
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks) asm volatile("v_xor_b32 %0, 0x10000, %0" : "+v"(rb[ks]));     // B reads of this K-tile are issued: other slot group
                     } else {
@@ -766,6 +786,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- M half: one C quadrant x K = 64
                     constexpr int qa = (q >= 2) ? 1 : 0, qb = (q == 1 || q == 2) ? 1 : 0;
+                    if (!(hmode && ht_qa != qa)) {        // (half-tile item: the other quadrant row's MFMAs are not this workgroup's)
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
@@ -776,6 +797,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             else acc[qa * 2 + ii][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ii][ks], bf, acc[qa * 2 + ii][qb], 0, 0, 0);
                         }
                     __builtin_amdgcn_s_setprio(0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
@@ -825,7 +847,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 #pragma unroll
                 for (int j = 0; j < G::TN; ++j) {
                     const int col = col0 + j * 32 + l31;
-                    if (col >= p.N) continue;
+                    if (col >= p.N || (hmode && (i >> 1) != ht_qa)) continue;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = row0 + i * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
@@ -1253,6 +1275,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     }
 #pragma unroll
                     for (int i = 0; i < G::TM; ++i) {
+                        if (hmode && (i >> 1) != ht_qa) continue;       // half-tile item: the other workgroup's rows
 #pragma unroll
                         for (int j = 0; j < G::TN; ++j)
 #pragma unroll
@@ -1316,6 +1339,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     for (int half = 0; half < G::TM / 2; ++half)
 #pragma unroll
                         for (int j = 0; j < G::TN; ++j) {
+                            if (hmode && half != ht_qa) continue;
 #pragma unroll
                             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -1365,6 +1389,8 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
                                  : (ring_env && ((ring_mask >> epilogue) & 1) && p.K >= 128 && p.K % 128 == 0);      // (conv: K = 9 cv_cin, an even number of 64-wide K-tiles)
     (void)use_ring;
     GemmParams pg = p;
+    static const bool half_tail = !(getenv("TLD_GEMM_HALFTAIL") && atoi(getenv("TLD_GEMM_HALFTAIL")) == 0);     // A/B knob
+    pg.half_tail = half_tail ? 1 : 0;
     if ((epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
         pg.xcd_ngroups = 2;
 #define TLD_L256P_(E, F8) TLD_L256P__(E, F8, false)
