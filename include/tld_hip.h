@@ -32,7 +32,8 @@ typedef struct tld_config {
     int32_t image_size;
     int32_t noise_embed_dims;
     int32_t patch_size;
-    int32_t embed_dim;        /* multiple of 128, <= 896 (inference engine; the row kernels' LDS tables) / <= 1024 (training): heads = embed_dim / 64 */
+    int32_t embed_dim;        /* any multiple of the head width 64 up to 1024: heads = embed_dim / 64 (tld/transformer_blocks.py:126-128);
+                                 the training engine (tld_train_*) takes multiples of 128 */
     int32_t n_layers;
     int32_t text_emb_size;
     int32_t n_channels;
@@ -90,8 +91,9 @@ TLD_API int tld_denoiser_forward(tld_engine* e, const void* x, const void* noise
  *           transformer_latent_diffusion_amd/schedule.py (host float64 algebra of :50-57,:72-81)
  *   out_latent [batch, C, S, S] fp32 device: x0_pred incl. sharp_f/bright_f shifts (:88-89)
  *   trace_x0 / trace_xt: optional device buffers [n_levels-1, batch, C, S, S] fp32 (NULL to skip)
- * batch*2 must be <= max_batch.  The call synchronises the stream once, before the first step,
- * after uploading its host-built tables; the steps themselves are enqueued asynchronously. */
+ * batch*2 must be <= max_batch.  The call does NOT synchronise the stream: its host-built tables (sigma per level, token-row
+ * indices) travel through a pinned staging buffer owned by the engine, and only a later tld_sample on the same engine waits (on
+ * an event, long complete by then) before refilling it; all steps are enqueued asynchronously on hip_stream. */
 TLD_API int tld_sample(tld_engine* e, const void* x_T, const void* labels, const float* coeffs, int32_t n_levels,
                float class_guidance, float sharp_f, float bright_f, void* out_latent, int32_t batch,
                void* trace_x0, void* trace_xt, void* hip_stream);

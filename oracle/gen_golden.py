@@ -25,6 +25,9 @@ Fixtures:
                           the first norm1): stresses LayerNorm statistics (the engine's folded LayerNorm-1 / -3 paths)
   g11_100m_512px_traj.npz C3 sampler: 100M model at image_size=64, 35-step CFG=6 DPM-2M end latent, B=1
   g14_100m_1024px_traj.npz C4 sampler: image_size=128 (4096 tokens), 35-step CFG=6 DPM-2M end latent, B=1 (fp32)
+  g16_config_sweep.npz    small (L=2, B=2) forwards over the constructor domain the goldens above do not touch: embed_dim 192 ... 1024
+                          (every multiple of 64 the reference accepts through n_heads = embed_dim // 64, transformer_blocks.py:126-128),
+                          n_channels=8, patch_size=4, mlp_multiplier=2, text_emb_size=512, 64- and 1024-token grids off the 100 M width
 
 Usage: python oracle/gen_golden.py            (all fixtures)
        python oracle/gen_golden.py g9 g11     (only the named ones; names are matched by prefix)
@@ -315,6 +318,47 @@ def _c4():
     return c4
 
 
+# (tag, DenoiserConfig kwargs): every case is L = 2, B = 2; weights = synth_state_dict(cfg, 16), inputs seeded by the case index
+SWEEP_CASES = [
+    ("d192", dict(image_size=32, embed_dim=192)),
+    ("d256", dict(image_size=32, embed_dim=256)),
+    ("d320", dict(image_size=32, embed_dim=320)),
+    ("d384", dict(image_size=32, embed_dim=384)),
+    ("d448", dict(image_size=32, embed_dim=448)),
+    ("d512", dict(image_size=32, embed_dim=512)),
+    ("d640", dict(image_size=32, embed_dim=640)),
+    ("d896", dict(image_size=32, embed_dim=896)),
+    ("d1024", dict(image_size=32, embed_dim=1024)),
+    ("c8", dict(image_size=32, embed_dim=256, n_channels=8)),                    # README.md:161 (outpainting model: 8 latent channels)
+    ("c8_d768", dict(image_size=32, embed_dim=768, n_channels=8)),
+    ("p4", dict(image_size=64, embed_dim=256, patch_size=4)),                    # 16 x 16 tokens of 4 x 4 patches, patch_dim 64
+    ("p1", dict(image_size=16, embed_dim=256, patch_size=1)),                    # one latent pixel per token, patch_dim 4
+    ("mlp2", dict(image_size=32, embed_dim=256, mlp_multiplier=2)),
+    ("mlp2_d768", dict(image_size=32, embed_dim=768, mlp_multiplier=2)),
+    ("text512", dict(image_size=32, embed_dim=256, text_emb_size=512)),
+    ("ne128", dict(image_size=32, embed_dim=256, noise_embed_dims=128)),
+    ("n64_d256", dict(image_size=16, embed_dim=256)),                            # 64 tokens
+    ("n64_d768", dict(image_size=16, embed_dim=768)),
+    ("n1024_d256", dict(image_size=64, embed_dim=256)),                          # 1024 tokens
+    ("n1024_d384", dict(image_size=64, embed_dim=384)),
+]
+
+
+def sweep_fixture():
+    d = {"tags": np.array([t for t, _ in SWEEP_CASES])}
+    for i, (tag, kw) in enumerate(SWEEP_CASES):
+        cfg = DenoiserConfig(n_layers=2, **kw)
+        m, ck = build_ref(cfg, 16)
+        x, sigma, label = inputs(cfg, 2, 1600 + i)
+        x0 = m(x, sigma, label)
+        d[f"{tag}_cfg"] = cfg_arr(cfg)
+        d[f"{tag}_checksum"] = np.array(ck)
+        d[f"{tag}_x"], d[f"{tag}_sigma"], d[f"{tag}_label"], d[f"{tag}_x0"] = x.numpy(), sigma.numpy(), label.numpy(), x0.numpy()
+        print(f"sweep {tag}: {asdict(cfg)}  |x0| rms {float(x0.pow(2).mean().sqrt()):.4f}")
+    d["weight_seed"] = np.int64(16)
+    save("g16_config_sweep.npz", **d)
+
+
 FIXTURES = {
     "g1": lambda: forward_fixture("g1_tiny32_forward.npz", DenoiserConfig(image_size=32, n_channels=4), 1, 3, 11, stages=True),
     "g2": sampler_fixture,
@@ -327,6 +371,7 @@ FIXTURES = {
     "g9": ln_stress_fixture,
     "g11": c3_traj_fixture,
     "g14": c4_traj_fixture,
+    "g16": sweep_fixture,
 }
 
 if __name__ == "__main__":

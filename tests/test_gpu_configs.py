@@ -181,6 +181,11 @@ def test_checkpoint_file_into_engine_512px(tmp_path):
     ya = a.to(_dev())(_t(x.numpy()), _t(sg.numpy()), _t(lab.numpy()))
     yb = b.to(_dev())(_t(x.numpy()), _t(sg.numpy()), _t(lab.numpy()))
     assert ya.shape == (2, 4, 64, 64) and torch.isfinite(ya).all() and torch.equal(ya, yb)
+    # ... and both are the forward of the fp32 restatement on the resampled state_dict (a resampler / key-mapping slip common to the two
+    # engine-side loads would cancel in the comparison above)
+    from oracle.torch_ref import TorchRefDenoiser
+    ref = TorchRefDenoiser(asdict(big), {k: v.numpy() for k, v in upsample_pos_embed(sd, 64).items()})(x, sg, lab).numpy()
+    assert rel_rms(ya.cpu().numpy(), ref) <= FWD_TOL, rel_rms(ya.cpu().numpy(), ref)
     # the table really was resampled (1024 rows from 256) and it matters: the un-resampled small model at its own size differs
     assert a.state_dict()["denoiser_trans_block.pos_embed.weight"].shape == (1024, 768)
 

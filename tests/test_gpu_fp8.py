@@ -18,7 +18,7 @@ from test_gpu_parity import _dev, _t
 
 pytestmark = pytest.mark.gpu
 
-FP8_TRAJ_TOL = 1.5e-1     # 35-step CFG-6 end latent rel-rms vs the fp32 reference trajectory (g14; stated by this build -- the reference has no fp8 mode)
+FP8_TRAJ_TOL = 8e-2       # 35-step CFG-6 end latent rel-rms vs the fp32 reference trajectory (g14; stated by this build -- the reference has no fp8 mode; measured 3.8e-2 .. 4.0e-2: twice that)
 FP8_FWD_TOL = 6e-2        # forward rel-rms vs the fp32 reference with all QKV / MLP GEMMs in MX-fp8 (measured 2.5e-2 .. 4.6e-2: DESIGN.md 4.4)
 
 
@@ -107,7 +107,7 @@ def test_fp8_c4_sampler_shape_runs():
 def test_fp8_c4_trajectory_vs_fp32_reference():
     """C4 end to end: 35 steps + CFG 6 at 1024 px (4096 tokens) with MX-fp8 QKV / MLP GEMMs against the reference's fp32 trajectory
     (g14).  The reference has no fp8 path, so this tolerance is the build's own statement (unpinned by the reference): first CFG
-    prediction <= FP8_FWD_TOL (6e-2), 35-step end latent <= FP8_TRAJ_TOL (1.5e-1); the bf16 engine meets 2e-2 / 6e-2 on the same
+    prediction <= FP8_FWD_TOL (6e-2), 35-step end latent <= FP8_TRAJ_TOL (8e-2); the bf16 engine meets 2e-2 / 6e-2 on the same
     fixture (test_gpu_configs.py::test_c4_sampler_1024px_bf16)."""
     from transformer_latent_diffusion_amd import DiffusionGenerator
     g = load_golden("g14_100m_1024px_traj.npz")

@@ -109,6 +109,31 @@ def test_forward_vs_golden(name):
     assert np.isfinite(out).all() and r <= FWD_TOL, r
 
 
+def _sweep_tags():
+    return [str(t) for t in load_golden("g16_config_sweep.npz")["tags"]]
+
+
+@pytest.mark.parametrize("tag", _sweep_tags())
+def test_forward_vs_golden_config_sweep(tag):
+    """g16: every shape switch of the engine (LayerNorm folds, fused depthwise epilogue, row-kernel layouts, GEMM tile widths, attention
+    variants) against the reference's own forward: embed_dim 192 ... 1024 (n_heads = embed_dim // 64, transformer_blocks.py:126-128),
+    n_channels 8, patch sizes 1 / 4, mlp_multiplier 2, text_emb_size 512, noise_embed_dims 128, 64- and 1024-token grids."""
+    from transformer_latent_diffusion_amd import Denoiser
+    g = load_golden("g16_config_sweep.npz")
+    cfg = cfg_from_arr(g[f"{tag}_cfg"])
+    sd = synth_weights(cfg, g["weight_seed"], g[f"{tag}_checksum"])
+    m = Denoiser(**asdict(cfg)).to(_dev())
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    out = m(_t(g[f"{tag}_x"]), _t(g[f"{tag}_sigma"]), _t(g[f"{tag}_label"])).cpu().numpy()
+    assert out.shape == g[f"{tag}_x0"].shape
+    r = rel_rms(out, g[f"{tag}_x0"])
+    assert np.isfinite(out).all() and r <= FWD_TOL, (tag, r)
+    # a larger batch of the same rows (other tile / round counts of every GEMM) reproduces them bit for bit
+    rep = 9
+    big = m(_t(np.tile(g[f"{tag}_x"], (rep, 1, 1, 1))), _t(np.tile(g[f"{tag}_sigma"], (rep, 1))), _t(np.tile(g[f"{tag}_label"], (rep, 1)))).cpu().numpy()
+    assert np.array_equal(big[:2], out) and np.array_equal(big[-2:], out), tag
+
+
 def test_forward_vs_oracle_random_inputs():
     from oracle.oracle import OracleDenoiser
     g = load_golden("g1_tiny32_forward.npz")
@@ -267,8 +292,8 @@ def test_abi_error_paths_on_device():
     cfg_, sd, m = _engine(g)
     m.reserve(4)
     assert L.tld_engine_set_gemm_dtype(m._engine, 1) != 0 and b"before" in L.tld_last_error()
-    bad = _lib.TldConfig(16, 256, 2, 1024, 1, 768, 4, 4, 8, 0)            # d = 1024: the row kernels' LDS tables do not fit
-    assert L.tld_engine_create(C.byref(bad), C.byref(h)) != 0 and b"LDS" in L.tld_last_error()
+    bad = _lib.TldConfig(32, 256, 4, 256, 1, 768, 8, 4, 8, 0)             # patch_dim = 8 * 4 * 4 = 128 > 64 (d = 1024 is a parity test now: g16)
+    assert L.tld_engine_create(C.byref(bad), C.byref(h)) != 0 and b"patch_dim" in L.tld_last_error()
 
 
 def test_bf16_io_matches_fp32_io():
@@ -283,6 +308,31 @@ def test_bf16_io_matches_fp32_io():
     o32r = m(xb.float(), s.bfloat16().float(), lb.float())
     assert rel_rms(ob.float().cpu().numpy(), o32r.cpu().numpy()) <= 1e-2
     assert torch.isfinite(o32).all()
+
+
+def test_fp16_io_vs_fp32_golden():
+    """DenoiserLoad.dtype may be torch.float16 (tld/configs.py:33-37; the README's timings are fp16, README.md:133): half tensors in,
+    half tensor out.  fp16 keeps 11 bits of sigma (the sinusoid's phase, up to 2 pi 1000 sigma rad, moves by O(1) rad under that rounding),
+    so the comparison is against the fp32 reference run on the ROUNDED inputs: the g1 model through the fp32 restatement."""
+    from oracle.torch_ref import TorchRefDenoiser
+    g = load_golden("g1_tiny32_forward.npz")
+    cfg, sd, m = _engine(g)
+    x, s, lab = _t(g["x"]).half(), _t(g["sigma"]).half(), _t(g["label"]).half()
+    out = m(x, s, lab)
+    assert out.dtype == torch.float16 and out.shape == x.shape
+    ref = TorchRefDenoiser(asdict(cfg), sd)(x.float().cpu(), s.float().cpu(), lab.float().cpu()).numpy()
+    r = rel_rms(out.float().cpu().numpy(), ref)
+    assert r <= FWD_TOL, r
+    # and it is the fp32-I/O result on the same rounded inputs, rounded once more on the way out
+    o32 = m(x.float(), s.float(), lab.float())
+    assert rel_rms(out.float().cpu().numpy(), o32.cpu().numpy()) <= 2e-3
+    # 100 M width too (the engine's production tile shapes)
+    g5 = load_golden("g5_100m.npz")
+    cfg5, sd5, m5 = _engine(g5)
+    x5, s5, l5 = _t(g5["x"]).half(), _t(g5["sigma"]).half(), _t(g5["label"]).half()
+    o5 = m5(x5, s5, l5)
+    ref5 = TorchRefDenoiser(asdict(cfg5), sd5)(x5.float().cpu(), s5.float().cpu(), l5.float().cpu()).numpy()
+    assert o5.dtype == torch.float16 and rel_rms(o5.float().cpu().numpy(), ref5) <= FWD_TOL
 
 
 _FALLBACK_SNIPPET = r"""

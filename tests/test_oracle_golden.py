@@ -142,3 +142,25 @@ def test_g11_c3_trajectory_fixture_is_consistent_with_g7():
     g7 = load_golden("g7_100m_512px.npz")
     assert str(g["weight_checksum"]) == str(g7["weight_checksum"])
     assert g["traj_latent"].shape == (1, 4, 64, 64) and np.isfinite(g["traj_latent"]).all()
+
+
+# ---- g16: the constructor domain off the two golden widths (embed_dim 192 .. 1024, n_channels 8, patch sizes 1 / 4, mlp_multiplier 2,
+# text_emb_size 512, noise_embed_dims 128, 64- / 1024-token grids).  Both restatements are pinned on every case. ----
+def _sweep_cases():
+    g = load_golden("g16_config_sweep.npz")
+    return [str(t) for t in g["tags"]]
+
+
+@pytest.mark.parametrize("tag", _sweep_cases())
+def test_g16_config_sweep_both_restatements(tag):
+    import torch
+    from dataclasses import asdict
+    from oracle.torch_ref import TorchRefDenoiser
+    g = load_golden("g16_config_sweep.npz")
+    cfg = cfg_from_arr(g[f"{tag}_cfg"])
+    sd = synth_weights(cfg, g["weight_seed"], g[f"{tag}_checksum"])
+    x, s, lab, x0 = g[f"{tag}_x"], g[f"{tag}_sigma"], g[f"{tag}_label"], g[f"{tag}_x0"]
+    out_c = OracleDenoiser(cfg, sd)(x, s, lab)
+    assert max_abs(out_c, x0) <= 1e-4 and rel_rms(out_c, x0) <= 1e-5, ("C", tag, max_abs(out_c, x0), rel_rms(out_c, x0))
+    out_t = TorchRefDenoiser(asdict(cfg), sd)(torch.from_numpy(x), torch.from_numpy(s), torch.from_numpy(lab)).numpy()
+    assert max_abs(out_t, x0) <= 1e-4 and rel_rms(out_t, x0) <= 1e-5, ("torch", tag, max_abs(out_t, x0), rel_rms(out_t, x0))

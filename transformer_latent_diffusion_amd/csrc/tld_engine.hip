@@ -454,9 +454,9 @@ const char* tld_last_error(void) { return g_err; }
 int tld_engine_create(const tld_config* c, tld_engine** out) {
     if (!c || !out) return fail(TLD_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (c->embed_dim <= 0 || c->embed_dim % 128 != 0 || c->embed_dim > 896)
-        return fail(TLD_ERR_INVALID, "embed_dim=%d unsupported: must be a multiple of 128, <= 896 "
-                    "(head_dim is 64, row kernels own 128-feature groups and keep per-workgroup tables in <= 64 KiB of LDS)", c->embed_dim);
+    if (c->embed_dim <= 0 || c->embed_dim % 64 != 0 || c->embed_dim > 1024)
+        return fail(TLD_ERR_INVALID, "embed_dim=%d unsupported: must be a multiple of the head width 64 (n_heads = embed_dim // 64, "
+                    "tld/transformer_blocks.py:126-128) and <= 1024 (the row kernels hold a token row in 8 x 128-feature register groups)", c->embed_dim);
     if (c->patch_size <= 0 || c->image_size % c->patch_size != 0)
         return fail(TLD_ERR_INVALID, "image_size=%d must be divisible by patch_size=%d", c->image_size, c->patch_size);
     const int grid = c->image_size / c->patch_size, ntok = grid * grid;
@@ -478,10 +478,10 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (c->device_id < 0 || c->device_id >= ndev) return fail(TLD_ERR_INVALID, "device_id %d out of range (%d devices)", c->device_id, ndev);
-    {   // the row kernels keep per-workgroup tables in dynamic LDS (no opt-in above 64 KiB is requested for them)
+    {   // the row kernels keep per-workgroup tables in dynamic LDS (opted in above the 64-KiB default; a CU has 160 KiB)
         const long d = c->embed_dim, H = d / 64;
         const long embed_lds = (pd * d + (long)pd * pd) * 4, tail_lds = pd * d * 4, cross_lds = (H * d + 2 * d + H) * 4;
-        const long lim = 64 * 1024;
+        const long lim = 160 * 1024;
         if (embed_lds > lim || tail_lds > lim || cross_lds > lim)
             return fail(TLD_ERR_INVALID, "embed_dim=%d with patch_dim=%d needs %ld / %ld / %ld bytes of LDS in the embed / "
                         "out-proj / cross-attention row kernels (limit %ld each): reduce patch_size*patch_size*n_channels "

@@ -8,7 +8,9 @@
 //   dwconv_gelu_kernel  depthwise 3x3 + bias + exact GELU, channels-last              tld/transformer_blocks.py:96-103
 //
 // Row layout: a wave owns one token row of d features; lane l holds features {2l, 2l+1} + 128*j
-// (float2 per access, 512 B per wave-instruction), so d must be a multiple of 128.
+// (float2 per access, 512 B per wave-instruction).  d = 128 NJ, or 128 NJ - 64 (template flag HALF: embed_dim is any
+// multiple of the head width 64, transformer_blocks.py:126-128): the last group then holds 64 features in lanes 0-31
+// and lanes 32-63 carry zeros through every sum and skip their loads / stores (`live`).
 #include "tld_common.h"
 #include <cstdlib>
 
@@ -20,10 +22,10 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // Workgroup = 32 token rows (8 per wave); the Linear(pd -> d) weight table [pd][d] fp32 (49 KB at d = 768)
 // is staged in LDS once per workgroup -- read per row from L1/L2 it made the kernel L1-bandwidth bound.
-template <int NJ>
+template <int NJ, bool HALF>
 __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int d = NJ * 128;
+    constexpr int d = NJ * 128 - (HALF ? 64 : 0);
     float* wt = reinterpret_cast<float*>(smem);                  // [pd][d]
     float* cwt = wt + p.pd * d;                                  // [C p p][pd]  conv weight, transposed (lane = output)
     for (int i = threadIdx.x; i < p.pd * d / 4; i += 256)
@@ -35,6 +37,8 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool live_last = !HALF || lane < 32;                   // does this lane hold features of the last 128-group?
+    auto live = [&](int j) { return j + 1 < NJ || live_last; };
     const int pp = p.p * p.p, cpp = p.C * pp;
     const int total = p.batch * p.ntok;
     // per-lane constants
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
 
         float2 e[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) e[j] = *reinterpret_cast<const float2*>(p.lin_b + j * 128 + 2 * lane);
+        for (int j = 0; j < NJ; ++j) e[j] = live(j) ? *reinterpret_cast<const float2*>(p.lin_b + j * 128 + 2 * lane) : make_float2(0.f, 0.f);
         auto lin_tap = [&](int o, const float2 (&w)[NJ]) {
             const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pn), o));
 #pragma unroll
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
         auto lin_load = [&](int o, float2 (&w)[NJ]) {
             const float* wrow = wt + o * d + 2 * lane;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) w[j] = *reinterpret_cast<const float2*>(wrow + j * 128);
+            for (int j = 0; j < NJ; ++j) w[j] = live(j) ? *reinterpret_cast<const float2*>(wrow + j * 128) : make_float2(0.f, 0.f);
         };
         {
             int o = 0;
@@ -112,11 +116,15 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
         const float mean2 = wave_sum(s) / (float)d;
         float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { e[j].x -= mean2; e[j].y -= mean2; q += e[j].x * e[j].x + e[j].y * e[j].y; }
+        for (int j = 0; j < NJ; ++j) {
+            if (live(j)) { e[j].x -= mean2; e[j].y -= mean2; }
+            q += e[j].x * e[j].x + e[j].y * e[j].y;
+        }
         const float rstd2 = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
         float ssum = 0.f, ssq = 0.f;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
+            if (!live(j)) continue;
             const int n = j * 128 + 2 * lane;
             const float2 g = *reinterpret_cast<const float2*>(p.ln2_w + n);
             const float2 bb = *reinterpret_cast<const float2*>(p.ln2_b + n);
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(256) void embed_kernel(EmbedParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int NJ>
+template <int NJ, bool HALF>
 __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const resid_t* __restrict__ x,
                                                              const float* __restrict__ g,
                                                              const float* __restrict__ b,
@@ -145,20 +153,26 @@ __global__ __launch_bounds__(256) void layernorm_bf16_kernel(const resid_t* __re
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
+    const bool live_last = !HALF || lane < 32;
+    auto live = [&](int j) { return j + 1 < NJ || live_last; };
     float2 v[NJ];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        v[j] = rs_load2(x + (size_t)row * d + j * 128 + 2 * lane);
+        v[j] = live(j) ? rs_load2(x + (size_t)row * d + j * 128 + 2 * lane) : make_float2(0.f, 0.f);
         s += v[j].x + v[j].y;
     }
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { v[j].x -= mean; v[j].y -= mean; q += v[j].x * v[j].x + v[j].y * v[j].y; }
+    for (int j = 0; j < NJ; ++j) {
+        if (live(j)) { v[j].x -= mean; v[j].y -= mean; }
+        q += v[j].x * v[j].x + v[j].y * v[j].y;
+    }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + kLnEps);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
+        if (!live(j)) continue;
         const int n = j * 128 + 2 * lane;
         const float2 gg = *reinterpret_cast<const float2*>(g + n);
         const float2 bb = *reinterpret_cast<const float2*>(b + n);
@@ -258,10 +272,10 @@ __global__ __launch_bounds__(256) void layernorm_mx8_kernel(const resid_t* __res
 // (token row, head), prepared once on the conditioning path (wq table, LN2 gamma folded in, LN2 beta
 // contribution in bwq).  The sub-block therefore needs no GEMM: per row it is 12 dot products of
 // the centred row against LDS-resident vectors, a sigmoid per head, and a blend of the two value rows.
-template <int NJ>
+template <int NJ, bool HALF>
 __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int chunks_per_sample) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int d = NJ * 128, H = NJ * 2;
+    constexpr int d = NJ * 128 - (HALF ? 64 : 0), H = d / 64;
     constexpr float inv_d = 1.0f / (float)d;
     float* wd = reinterpret_cast<float*>(smem);          // [H][d]  wq_label - wq_noise (gamma folded)
     float* vn = wd + H * d;                              // [d]     value row of the noise token
@@ -280,6 +294,8 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool upper = lane >= 32;
+    const bool live_last = !HALF || !upper;
+    auto live = [&](int j) { return j + 1 < NJ || live_last; };
     // input rows: normally the same rows; with CFG layer-0 sharing the cond and uncond samples read the one copy
     const resid_t* xin = p.x_in ? p.x_in : p.x;
     const size_t obase = (size_t)b * p.ntok;
@@ -293,8 +309,13 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = j * 128 + 2 * lane;
-            xv[j] = rs_load2(xin + row * d + n);
-            av[j] = *reinterpret_cast<const bf16x2*>(p.att + row * d + n);
+            if (live(j)) {
+                xv[j] = rs_load2(xin + row * d + n);
+                av[j] = *reinterpret_cast<const bf16x2*>(p.att + row * d + n);
+            } else {
+                xv[j] = make_float2(0.f, 0.f);
+                av[j] = bf16x2{(bf16)0.f, (bf16)0.f};
+            }
         }
     };
     int pr = pp0 + wid;
@@ -322,7 +343,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
     // lane's features of group j belong to head 2j + (lane >> 5)
     float bwl[NJ];
 #pragma unroll
-    for (int hh = 0; hh < NJ; ++hh) bwl[hh] = bw[2 * hh + (upper ? 1 : 0)];
+    for (int hh = 0; hh < NJ; ++hh) bwl[hh] = live(hh) ? bw[2 * hh + (upper ? 1 : 0)] : 0.f;
 
     for (; pr < pp1; pr += 4) {
         f32x2 v[2][NJ];
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
-                    *reinterpret_cast<f32x2*>(p.sa_out + (row + u) * d + j * 128 + 2 * lane) = v[u][j];
+                    if (live(j)) *reinterpret_cast<f32x2*>(p.sa_out + (row + u) * d + j * 128 + 2 * lane) = v[u][j];
         }
         float mean[2], rstd[2];
 #pragma unroll
@@ -359,7 +380,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
             f32x2 q2 = {0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                c[u][j] = v[u][j] - mean[u];
+                c[u][j] = live(j) ? v[u][j] - mean[u] : f32x2{0.f, 0.f};
                 q2 = __builtin_elementwise_fma(c[u][j], c[u][j], q2);
             }
             rstd[u] = __builtin_amdgcn_rsqf(fmaf(wave_sum(q2[0] + q2[1]), inv_d, kLnEps));
@@ -374,10 +395,11 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
             f32x2 acc[2][2] = {{{0.f, 0.f}, {0.f, 0.f}}, {{0.f, 0.f}, {0.f, 0.f}}};
             const float* w0 = wd + (2 * hh) * d + 2 * lane;
             const float* w1 = w0 + d;
+            const bool h1 = !HALF || hh + 1 < NJ;              // head 2 hh + 1 exists
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const f32x2 a = *reinterpret_cast<const f32x2*>(w0 + j * 128);
-                const f32x2 e = *reinterpret_cast<const f32x2*>(w1 + j * 128);
+                const f32x2 a = live(j) ? *reinterpret_cast<const f32x2*>(w0 + j * 128) : f32x2{0.f, 0.f};
+                const f32x2 e = (h1 && live(j)) ? *reinterpret_cast<const f32x2*>(w1 + j * 128) : f32x2{0.f, 0.f};
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     acc[u][0] = __builtin_elementwise_fma(c[u][j], a, acc[u][0]);
@@ -400,6 +422,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
             f32x2 s2 = {0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
+                if (!live(j)) continue;
                 const int n = j * 128 + 2 * lane;
                 const f32x2 a = *reinterpret_cast<const f32x2*>(vn + n);
                 const f32x2 dd = *reinterpret_cast<const f32x2*>(vdiff + n);
@@ -415,6 +438,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
             f32x2 q2 = {0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
+                if (!live(j)) continue;
                 v[u][j] -= mean3[u];
                 q2 = __builtin_elementwise_fma(v[u][j], v[u][j], q2);
             }
@@ -422,6 +446,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
+            if (!live(j)) continue;
             const int n = j * 128 + 2 * lane;
             const f32x2 gg = *reinterpret_cast<const f32x2*>(p.ln3_w + n);
             const f32x2 bb = *reinterpret_cast<const f32x2*>(p.ln3_b + n);
@@ -675,15 +700,17 @@ __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, 
 
 // ------------------------------------------------------------------------------------------------
 // out_proj + unpatchify.  16 tokens per wave, weights [pd][d] fp32 resident in LDS.
-template <int NJ>
+template <int NJ, bool HALF>
 __global__ __launch_bounds__(256) void tail_kernel(TailParams p, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int d = NJ * 128;
+    constexpr int d = NJ * 128 - (HALF ? 64 : 0);
     float* w = reinterpret_cast<float*>(smem);           // [pd][d]
     for (int i = threadIdx.x; i < p.pd * d / 4; i += 256)
         reinterpret_cast<float4*>(w)[i] = reinterpret_cast<const float4*>(p.w)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool live_last = !HALF || lane < 32;
+    auto live = [&](int j) { return j + 1 < NJ || live_last; };
     const int rows_per_wave = rows_per_block / 4;            // even
     const int total = p.batch * p.ntok;                      // even (ntok is)
     const int row_first = blockIdx.x * rows_per_block + wid * rows_per_wave;
@@ -692,7 +719,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailParams p, int rows_per_bl
     auto fetch = [&](int row, float2 (&v)[NJ]) {
         const int r = row < total ? row : total - 1;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) v[j] = rs_load2(p.tok + (size_t)r * d + j * 128 + 2 * lane);
+        for (int j = 0; j < NJ; ++j) v[j] = live(j) ? rs_load2(p.tok + (size_t)r * d + j * 128 + 2 * lane) : make_float2(0.f, 0.f);
     };
     fetch(row_first, nx[0]); fetch(row_first + 1, nx[1]);
     const float bias = p.b[lane < p.pd ? lane : 0];
@@ -714,7 +741,7 @@ __global__ __launch_bounds__(256) void tail_kernel(TailParams p, int rows_per_bl
                 const float* wrow = w + o * d + 2 * lane;
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
-                    const float2 ww = *reinterpret_cast<const float2*>(wrow + j * 128);
+                    const float2 ww = live(j) ? *reinterpret_cast<const float2*>(wrow + j * 128) : make_float2(0.f, 0.f);
 #pragma unroll
                     for (int u2 = 0; u2 < 2; ++u2)
                         part[u2][u] = fmaf(v[u2][j].x, ww.x, fmaf(v[u2][j].y, ww.y, part[u2][u]));
@@ -969,23 +996,36 @@ __global__ __launch_bounds__(256) void dwconv_gelu_tiled_kernel(const bf16* __re
 
 }  // namespace
 
-#define TLD_DISPATCH_NJ(nj, CALL)                                                                  \
+// d = 64 k (k = 1 .. 16): NJ = ceil(d / 128) feature groups per lane, HALF when the last one holds 64 features
+#define TLD_DISPATCH_NJ_(nj, HF, ...)                                                               \
     switch (nj) {                                                                                    \
-        case 1: { constexpr int NJ = 1; CALL; } break;                                              \
-        case 2: { constexpr int NJ = 2; CALL; } break;                                              \
-        case 3: { constexpr int NJ = 3; CALL; } break;                                              \
-        case 4: { constexpr int NJ = 4; CALL; } break;                                              \
-        case 5: { constexpr int NJ = 5; CALL; } break;                                              \
-        case 6: { constexpr int NJ = 6; CALL; } break;                                              \
-        case 7: { constexpr int NJ = 7; CALL; } break;                                              \
-        case 8: { constexpr int NJ = 8; CALL; } break;                                              \
+        case 1: { constexpr int NJ = 1; constexpr bool HALF = HF; __VA_ARGS__; } break;                    \
+        case 2: { constexpr int NJ = 2; constexpr bool HALF = HF; __VA_ARGS__; } break;                    \
+        case 3: { constexpr int NJ = 3; constexpr bool HALF = HF; __VA_ARGS__; } break;                    \
+        case 4: { constexpr int NJ = 4; constexpr bool HALF = HF; __VA_ARGS__; } break;                    \
+        case 5: { constexpr int NJ = 5; constexpr bool HALF = HF; __VA_ARGS__; } break;                    \
+        case 6: { constexpr int NJ = 6; constexpr bool HALF = HF; __VA_ARGS__; } break;                    \
+        case 7: { constexpr int NJ = 7; constexpr bool HALF = HF; __VA_ARGS__; } break;                    \
+        case 8: { constexpr int NJ = 8; constexpr bool HALF = HF; __VA_ARGS__; } break;                    \
         default: break;                                                                              \
     }
+#define TLD_DISPATCH_D(dd, ...)                                                                      \
+    do {                                                                                             \
+        if ((dd) % 128) TLD_DISPATCH_NJ_(((dd) + 127) / 128, true, __VA_ARGS__) else TLD_DISPATCH_NJ_((dd) / 128, false, __VA_ARGS__)  \
+    } while (0)
+
+// dynamic LDS above the 64-KiB default needs an opt-in per kernel and device (embed / out-proj / cross-attention tables at d = 1024)
+#define TLD_LDS_OPT_IN(KERNEL, bytes)                                                                \
+    do {                                                                                             \
+        static PerDeviceMax optin;                                                                   \
+        if ((bytes) > 64 * 1024 && optin.raise(bytes))                                               \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+    } while (0)
 
 void launch_embed(const EmbedParams& p, hipStream_t s) {
     const int rows = p.batch * p.ntok;
     const int lds = (p.pd * p.d + p.pd * p.C * p.p * p.p) * (int)sizeof(float);
-    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(embed_kernel<NJ>, dim3((rows + 31) / 32), dim3(256), lds, s, p));
+    TLD_DISPATCH_D(p.d, { TLD_LDS_OPT_IN((embed_kernel<NJ, HALF>), lds); hipLaunchKernelGGL((embed_kernel<NJ, HALF>), dim3((rows + 31) / 32), dim3(256), lds, s, p); });
 }
 
 void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf16* out, int M, int d,
@@ -995,7 +1035,7 @@ void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf1
     if (q4 && d == 512) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
     if (q4 && d == 256) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
     if (q4 && d == 1024) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
-    TLD_DISPATCH_NJ(d / 128, hipLaunchKernelGGL(layernorm_bf16_kernel<NJ>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d));
+    TLD_DISPATCH_D(d, hipLaunchKernelGGL((layernorm_bf16_kernel<NJ, HALF>), dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d));
 }
 
 bool layernorm_mx8_supported(int d) { return d == 256 || d == 512 || d == 768; }      // (the engine's embed_dim limit is 896)
@@ -1045,14 +1085,14 @@ void launch_cross_row(const CrossRowParams& p_in, hipStream_t s) {
     if (q4 && p.d == 768) { hipLaunchKernelGGL((cross_row_q4_kernel<3, false>), grid, dim3(256), lds, s, p, (int)cps); return; }
     if (q4 && p.d == 512) { hipLaunchKernelGGL((cross_row_q4_kernel<2, false>), grid, dim3(256), lds, s, p, (int)cps); return; }
     if (q4 && p.d == 256) { hipLaunchKernelGGL((cross_row_q4_kernel<1, false>), grid, dim3(256), lds, s, p, (int)cps); return; }
-    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(cross_row_kernel<NJ>, grid, dim3(256), lds, s, p, (int)cps));
+    TLD_DISPATCH_D(p.d, { TLD_LDS_OPT_IN((cross_row_kernel<NJ, HALF>), lds); hipLaunchKernelGGL((cross_row_kernel<NJ, HALF>), grid, dim3(256), lds, s, p, (int)cps); });
 }
 
 void launch_tail(const TailParams& p, hipStream_t s) {
     const int rpb = 64;
     const int rows = p.batch * p.ntok;
     const int lds = p.pd * p.d * (int)sizeof(float);
-    TLD_DISPATCH_NJ(p.d / 128, hipLaunchKernelGGL(tail_kernel<NJ>, dim3((rows + rpb - 1) / rpb), dim3(256), lds, s, p, rpb));
+    TLD_DISPATCH_D(p.d, { TLD_LDS_OPT_IN((tail_kernel<NJ, HALF>), lds); hipLaunchKernelGGL((tail_kernel<NJ, HALF>), dim3((rows + rpb - 1) / rpb), dim3(256), lds, s, p, rpb); });
 }
 
 void launch_update(const UpdateParams& p, hipStream_t s) {
