@@ -346,11 +346,11 @@ print("REL", rel_rms(out, g["x0"]))
 """
 
 
-@pytest.mark.parametrize("knobs", [{"TLD_FOLD_LN3": "0"}, {"TLD_FOLD_LN1": "0"}, {"TLD_FUSE_DWCONV": "0"}, {"TLD_DOWN_BN384": "0"},
-                                   {"TLD_CROSS_Q4": "0", "TLD_LN_Q4": "0"}, {"TLD_SHARE_L0": "0", "TLD_ATTN_8W": "1"}])
+@pytest.mark.parametrize("knobs", [{"TLD_FOLD_LN3": "0"}, {"TLD_FOLD_LN1": "0"}, {"TLD_FUSE_DWCONV": "0", "TLD_SHARE_L0": "0"}])
 def test_fallback_paths_vs_golden(knobs):
-    """The A/B switches select older code paths that stay in the tree (and serve other shapes): each must still
-    reproduce the 100 M golden forward.  The switches are read once per process, hence the subprocess."""
+    """The engine's structural switches select the paths other SHAPES take by themselves (no LayerNorm folds off the 100 M width, separate
+    depthwise kernel off the 16 x 16 grid; g16 covers those shapes natively): at the 100 M width each must still reproduce the golden
+    forward.  (TLD_FUSE_QKV_ATTN=0 has a test of its own, test_gpu_configs.py.)  The switches are read when an engine is created."""
     import os
     import subprocess
     import sys

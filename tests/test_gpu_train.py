@@ -242,3 +242,76 @@ def test_graph_replay_equals_eager_steps(monkeypatch):
     l1, p1, g1 = run(True)
     assert not g0 and g1
     assert l0 == l1 and torch.equal(p0, p1)
+
+
+def test_graph_capture_refreshes_weights_and_pred_is_not_aliased(monkeypatch):
+    """two forward_backward calls in a row (gradient accumulation / reproducibility checks) make the capture happen with the engine's
+    weights_fresh flag SET; the refresh kernels must still be part of the graph, or every replay after an Adam step runs on stale bf16 weights.
+    Sequence fb, fb (captures), step, fb, step, fb in graph mode == the same sequence eagerly, bit for bit; returned predictions are copies."""
+    from transformer_latent_diffusion_amd import DenoiserConfig, Trainer
+    from transformer_latent_diffusion_amd.train import TrainConfig
+    cfg = DenoiserConfig(image_size=32, noise_embed_dims=256, patch_size=2, embed_dim=256, dropout=0, n_layers=2, text_emb_size=768, n_channels=4,
+                         mlp_multiplier=4)
+
+    def run(graph):
+        monkeypatch.setenv("TLD_TRAIN_GRAPH", "1" if graph else "0")
+        tr = Trainer(cfg, TrainConfig(batch_size=8), device="cuda:0", init_seed=3, max_batch=8)
+        g = torch.Generator().manual_seed(9)
+        batches = [(torch.randn(8, 4, 32, 32, generator=g), torch.rand(8, generator=g) * 0.9 + 0.05, torch.randn(8, 768, generator=g),
+                    torch.randn(8, 4, 32, 32, generator=g)) for _ in range(4)]
+        out = []
+        l, p = tr.forward_backward(*batches[0]); out.append((float(l), p))
+        l, p = tr.forward_backward(*batches[1]); out.append((float(l), p))        # second full-batch call: capture in graph mode
+        tr.optimizer_step()
+        l, p = tr.forward_backward(*batches[2]); out.append((float(l), p))
+        tr.optimizer_step()
+        l, p = tr.forward_backward(*batches[3]); out.append((float(l), p))
+        torch.cuda.synchronize()
+        return out, tr.grads.clone(), tr._graph is not None
+
+    e, ge, g0 = run(False)
+    r, gr, g1 = run(True)
+    assert not g0 and g1
+    for (le, pe), (lr, pr) in zip(e, r):
+        assert le == lr and torch.equal(pe, pr)
+    assert torch.equal(ge, gr)
+    assert r[1][1].data_ptr() != r[2][1].data_ptr() and not torch.equal(r[1][1], r[2][1])      # replays hand out copies
+
+
+def test_checkpoint_is_reference_format_and_resumes(tmp_path):
+    """The checkpoint dict is the reference's (tld/train.py:150-156): model_ema, torch.optim.Adam's state_dict layout, global_step -- and
+    Trainer.load_checkpoint resumes from it (tld/train.py:92-104): a run continued from the checkpoint takes the same steps as the original."""
+    from transformer_latent_diffusion_amd import DenoiserConfig, Trainer
+    from transformer_latent_diffusion_amd.train import TrainConfig
+    cfg = DenoiserConfig(image_size=32, n_channels=4)
+    tr = Trainer(cfg, TrainConfig(batch_size=4), device="cuda:0", init_seed=1, max_batch=4)
+    g = torch.Generator().manual_seed(2); rng = np.random.default_rng(3)
+    for _ in range(3):
+        tr.train_step(torch.randn(4, 4, 32, 32, generator=g), torch.randn(4, 768, generator=g), np_rng=rng, generator=g)
+    ck = tr.checkpoint()
+    assert set(ck) == {"model_ema", "opt_state", "global_step"} and ck["global_step"] == 3
+    osd = ck["opt_state"]
+    # torch.optim.Adam accepts it for a parameter list of the same shapes
+    ps = [torch.nn.Parameter(torch.zeros(s)) for _, s in tr.layout.values()]
+    opt = torch.optim.Adam(ps, lr=1e-3)
+    opt.load_state_dict(osd)
+    assert float(opt.state[ps[0]]["step"]) == 3.0 and opt.param_groups[0]["lr"] == tr.tc.lr
+    path = str(tmp_path / "ck.pth")
+    torch.save(ck, path)
+    # resume: the reference loads the EMA weights into the live model -- do the same to the original, then both continue identically
+    tr.load_checkpoint(ck)
+    tr2 = Trainer(cfg, TrainConfig(batch_size=4), device="cuda:0", init_seed=99, max_batch=4).load_checkpoint(path)
+    assert tr2.step == 3 and torch.equal(tr2.params, tr.params) and torch.equal(tr2.exp_avg, tr.exp_avg) and torch.equal(tr2.exp_avg_sq, tr.exp_avg_sq)
+    x, y = torch.randn(4, 4, 32, 32, generator=g), torch.randn(4, 768, generator=g)
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    l1 = tr.train_step(x, y, np_rng=np.random.default_rng(8), generator=g1)
+    l2 = tr2.train_step(x, y, np_rng=np.random.default_rng(8), generator=g2)
+    assert float(l1) == float(l2) and torch.equal(tr.params, tr2.params) and tr2.step == 4
+
+
+def test_trainer_refuses_dropout_and_resolves_current_device():
+    from transformer_latent_diffusion_amd import DenoiserConfig, Trainer
+    with pytest.raises(NotImplementedError):
+        Trainer(DenoiserConfig(image_size=32, n_channels=4, dropout=0.1), device="cuda:0")
+    tr = Trainer(DenoiserConfig(image_size=32, n_channels=4), device="cuda", max_batch=2)
+    assert tr.device == torch.device("cuda", torch.cuda.current_device()) and tr.params.device == tr.device

@@ -757,361 +757,6 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const bf16* __restrict__ 
 #endif
 }
 
-// =====================================================================================================================
-// attn_cross_kernel (round 3): self-attention + residual add + the whole cross-attention sub-block + residual add + LayerNorm-3
-// statistics for 256-token grids in ONE kernel -- replaces attn1_kernel followed by cross_row_q4_kernel
-// (tld/transformer_blocks.py:37-44,62-72,136-137).  The 50 MB `att` tensor is never written or read back and a launch per layer goes.
-//
-// Work split: one 4-wave workgroup per (sample, half of its tokens); a wave owns ONE 32-query tile and walks the H heads.  Per head the
-// K rows (DMA, double-buffered) and V^T (through registers) of the sample are staged once per workgroup and the wave runs attn1's body
-// (S^T = K Q^T with a lane per query, lane-local softmax, O^T = V^T P^T).  The head's 32 x 64 output never leaves the registers as
-// `att`: x1 = x + O is formed on the spot (lane = query row), rounded to the stored bf16 residual, written back to x IN PLACE (whole
-// 128-byte rows through the per-wave LDS patch), and consumed twice while still in the accumulator layout:
-//   * row statistics of LayerNorm-2 (sum, sum of squares of the stored values): lane-local, one lane^32 exchange at the end;
-//   * the H cross-attention logits of the row.  With two conditioning tokens the sub-block needs, per row and cross head h', the ONE number
-//     LN2(x1) . wd[h'] (wd = folded query vector of the label token minus the noise token's, CrossRowParams::wq): 768-long dot products,
-//     9216 MACs per row on the VALU in cross_row.  Here they ride on the matrix pipe: x1's bf16 values go from the accumulators straight
-//     into the B operand of four more MFMAs per head (A = wd's 64 columns of this head, bf16, laid out in the accumulators' row order),
-//     D[h'][query] accumulating over the heads; the LayerNorm enters afterwards as rstd (D - mean W1[h']) with W1 = the sum of the SAME
-//     bf16-rounded wd entries, so the common-mode part cancels exactly as in the LayerNorm folds of the GEMMs.
-// After the last head: p[h'] = sigmoid(logit), shared through a per-wave LDS table, and a second pass over the wave's 32 rows (wave per
-// row, the row kernels' 4-features-per-lane layout) adds p v_label + (1 - p) v_noise, stores the row and leaves its (mean, rstd) for the
-// up-projection's folded LayerNorm-3.  The rows it re-reads were written by this wave microseconds earlier (L2-resident).
-// One extra bf16 rounding of the residual stream per layer compared with cross_row (x1 is stored before the cross-attention output is
-// added): what the reference's own bf16 mode does at every residual add.
-constexpr int kAcKBytes = 256 * 128, kAcVStride = 256 * 2 + 8, kAcVBytes = 64 * kAcVStride;
-constexpr int kAcOffV = 2 * kAcKBytes, kAcOffW = kAcOffV + kAcVBytes;              // A-operand table of the logit MFMAs: [H][4 slices][2 hi][16 rows][8] bf16
-__host__ __device__ constexpr int ac_off_vn(int H) { return kAcOffW + H * 4 * 512; }                 // vn[d], vdiff[d] fp32
-__host__ __device__ constexpr int ac_off_ct(int H, int d) { return ac_off_vn(H) + 2 * d * 4; }       // W1[16], BW[16]
-__host__ __device__ constexpr int ac_off_pt(int H, int d) { return ac_off_ct(H, d) + 128; }          // per wave: P[32][16] fp32
-__host__ __device__ constexpr int ac_off_tp(int H, int d) { return ac_off_pt(H, d) + 4 * 2048; }     // per wave: 16 x 144 B transpose patch
-__host__ __device__ constexpr int ac_lds(int H, int d) { return ac_off_tp(H, d) + 4 * 2304; }
-
-template <int NQ>       // d = 256 NQ, H = 4 NQ
-__global__ __launch_bounds__(256, 1) void attn_cross_kernel(AttnCrossParams p) {
-    constexpr int d = NQ * 256, H = NQ * 4, NTOK = 256, KT = 8;
-    constexpr float inv_d = 1.0f / (float)d;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Vs = smem + kAcOffV;
-    char* WT = smem + kAcOffW;
-    float* vn = reinterpret_cast<float*>(smem + ac_off_vn(H));
-    float* vdiff = vn + d;
-    float* W1 = reinterpret_cast<float*>(smem + ac_off_ct(H, d));
-    float* BW = W1 + 16;
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hi = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.z, hq = blockIdx.x;
-    const int twod = 2 * d;
-    const size_t row_base = (size_t)b * NTOK;
-    const int q0 = (hq * 4 + wid) * 32;
-    float* PT = reinterpret_cast<float*>(smem + ac_off_pt(H, d) + wid * 2048);
-    char* TP = smem + ac_off_tp(H, d) + wid * 2304;
-
-    // ---- staging helpers (the 256-token attention kernel's)
-    auto load_q = [&](int h, bf16x8 (&q)[4]) {
-        const bf16* qp = p.qk + (row_base + q0 + l31) * twod + h * 64 + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) q[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-    };
-    auto dma_k = [&](int h) {
-        const bf16* kbase = p.qk + row_base * twod + d + h * 64;
-        char* Ks = smem + (h & 1) * kAcKBytes;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int r = (wid * 8 + it) * 8 + (lane >> 3);
-            const int clog = (lane & 7) ^ ((r >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (size_t)r * twod + clog * 8), (lptr_t)(Ks + (wid * 8 + it) * 1024), 16, 0, 0);
-        }
-    };
-    u32x4 vreg[8];
-    auto load_v = [&](int h) {
-        const bf16* vbase = p.vt + ((size_t)b * d + h * 64) * NTOK;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int pidx = it * 256 + threadIdx.x;
-            const int c = pidx >> 5, kc8 = pidx & 31;
-            vreg[it] = *reinterpret_cast<const u32x4*>(vbase + (size_t)c * NTOK + kc8 * 8);
-        }
-    };
-    auto store_v = [&]() {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int pidx = it * 256 + threadIdx.x;
-            const int c = pidx >> 5, kc8 = pidx & 31;
-            uint2* dst = reinterpret_cast<uint2*>(Vs + c * kAcVStride + kc8 * 16);
-            dst[0] = make_uint2(vreg[it][0], vreg[it][1]);
-            dst[1] = make_uint2(vreg[it][2], vreg[it][3]);
-        }
-    };
-
-    bf16x8 qnext[4];
-    load_q(0, qnext);
-    dma_k(0);
-    load_v(0);
-    // ---- per-sample tables
-    const int tn = p.noise_row[b], tl = p.label_row[b];
-    {
-        const float* wl = p.wq + (size_t)tl * H * d;
-        const float* wn = p.wq + (size_t)tn * H * d;
-        // A-operand fragments: entry (h, slice sl = 2 ct + s, hi, row h', e) <- wd[h'][h * 64 + ct * 32 + s * 16 + (e & 3) + 8 (e >> 2) + 4 hi]
-        for (int i = threadIdx.x; i < H * 4 * 2 * 16 * 8; i += 256) {
-            const int e = i & 7, hr = (i >> 3) & 15, hh = (i >> 7) & 1, sl = (i >> 8) & 3, h = i >> 10;
-            float v = 0.f;
-            if (hr < H) {
-                const int f = h * 64 + (sl >> 1) * 32 + (sl & 1) * 16 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                v = wl[(size_t)hr * d + f] - wn[(size_t)hr * d + f];
-            }
-            reinterpret_cast<bf16*>(WT)[i] = (bf16)v;
-        }
-        // W1[h'] = sum over all features of the ROUNDED wd[h'][.]: 16 threads (one DPP row) per h'
-        {
-            const int hr = threadIdx.x >> 4, part = threadIdx.x & 15;
-            float a = 0.f;
-            if (hr < H)
-                for (int f = part; f < d; f += 16) a += (float)(bf16)(wl[(size_t)hr * d + f] - wn[(size_t)hr * d + f]);
-            a = dpp_add<0xB1>(a); a = dpp_add<0x4E>(a); a = dpp_add<0x141>(a); a = dpp_add<0x140>(a);
-            if (part == 0) { W1[hr] = a; BW[hr] = hr < H ? p.bwq[(size_t)tl * H + hr] - p.bwq[(size_t)tn * H + hr] : 0.f; }
-        }
-        for (int i = threadIdx.x; i < d; i += 256) {
-            const float a = p.v[(size_t)tn * p.v_ld + i];
-            vn[i] = a;
-            vdiff[i] = p.v[(size_t)tl * p.v_ld + i] - a;
-        }
-    }
-
-    f32x16 D;                                  // rows (registers) = cross heads h', columns (lanes) = queries
-#pragma unroll
-    for (int r = 0; r < 16; ++r) D[r] = 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    bf16x4 x1prev[2][4];
-    // store the x1 values of head hh (bf16) back into the stream: whole 128-byte row segments through the wave's LDS patch, 16 rows at a time
-    auto flush_x1 = [&](int hh) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if ((l31 >> 4) == half) {
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq)
-                        *reinterpret_cast<bf16x4*>(TP + (l31 & 15) * 144 + ct * 64 + rq * 16 + hi * 8) = x1prev[ct][rq];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int r = it * 8 + (lane >> 3), c16 = lane & 7;
-                const u32x4 w = *reinterpret_cast<const u32x4*>(TP + r * 144 + c16 * 16);
-                *reinterpret_cast<u32x4*>(p.x + (row_base + q0 + half * 16 + r) * d + hh * 64 + c16 * 8) = w;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-    };
-#pragma unroll 1
-    for (int h = 0; h < H; ++h) {
-        const char* Ks = smem + (h & 1) * kAcKBytes;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own K pieces of head h, V^T registers (and the x1 stores of head h - 2: long done)
-        __syncthreads();                                   // everybody's K pieces; everybody is done with head h - 1 (V^T image, other K stage); tables (h == 0)
-        store_v();
-        if (h > 0) flush_x1(h - 1);
-        bf16x8 qf[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = qnext[ks];
-        if (h + 1 < H) { dma_k(h + 1); load_v(h + 1); load_q(h + 1, qnext); }
-        // ---- scores S^T = K Q^T (fragment reads pipelined one step ahead)
-        f32x16 st[KT];
-        {
-            auto kfrag = [&](int t, int ks) {
-                const int row = t * 32 + l31;
-                const int kc = ks * 2 + hi;
-                return *reinterpret_cast<const bf16x8*>(Ks + row * 128 + ((kc ^ ((row >> 1) & 7)) << 4));
-            };
-            bf16x8 fa[4], fb[4];
-            auto fetch = [&](int s2_, bf16x8 (&f)[4]) {
-                const int p2 = s2_ >> 1, h2 = s2_ & 1;
-                f[0] = kfrag(2 * p2, 2 * h2); f[1] = kfrag(2 * p2 + 1, 2 * h2);
-                f[2] = kfrag(2 * p2, 2 * h2 + 1); f[3] = kfrag(2 * p2 + 1, 2 * h2 + 1);
-            };
-            auto fire = [&](int s2_, const bf16x8 (&f)[4]) {
-                const int p2 = s2_ >> 1, h2 = s2_ & 1;
-                st[2 * p2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], qf[2 * h2], h2 ? st[2 * p2] : zero16, 0, 0, 0);
-                st[2 * p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], qf[2 * h2], h2 ? st[2 * p2 + 1] : zero16, 0, 0, 0);
-                st[2 * p2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], qf[2 * h2 + 1], st[2 * p2], 0, 0, 0);
-                st[2 * p2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[3], qf[2 * h2 + 1], st[2 * p2 + 1], 0, 0, 0);
-            };
-            fetch(0, fa);
-#pragma unroll
-            for (int s2_ = 0; s2_ < KT; s2_ += 2) {
-                fetch(s2_ + 1, fb);
-                __builtin_amdgcn_sched_barrier(0);
-                fire(s2_, fa);
-                __builtin_amdgcn_sched_barrier(0);
-                if (s2_ + 2 < KT) fetch(s2_ + 2, fa);
-                __builtin_amdgcn_sched_barrier(0);
-                fire(s2_ + 1, fb);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        float mx = st[0][0];
-#pragma unroll
-        for (int t = 0; t < KT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = mx * kScaleLog2e;
-        __syncthreads();                                   // the V^T image of head h is complete
-        // ---- O^T = V^T P^T
-        f32x16 o[2] = {zero16, zero16};
-        float l_run = 0.f;
-        {
-            auto vfrag = [&](int s2_, int ct) {
-                const char* vp = Vs + (ct * 32 + l31) * kAcVStride + (s2_ * 16 + hi * 4) * 2;
-                const uint2 v0 = *reinterpret_cast<const uint2*>(vp);
-                const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16);
-                union { uint4 u; bf16x8 v; } cvt;
-                cvt.u = make_uint4(v0.x, v0.y, v1.x, v1.y);
-                return cvt.v;
-            };
-            auto probs = [&](int s2_) {
-                bf16x8 pf;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(st[s2_ >> 1][(s2_ & 1) * 8 + e] * kScaleLog2e - m_new);
-                    l_run += pv;
-                    pf[e] = (bf16)pv;
-                }
-                return pf;
-            };
-            bf16x8 va[2], vb[2];
-            va[0] = vfrag(0, 0); va[1] = vfrag(0, 1);
-#pragma unroll
-            for (int s2_ = 0; s2_ < 2 * KT; s2_ += 2) {
-                vb[0] = vfrag(s2_ + 1, 0); vb[1] = vfrag(s2_ + 1, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    const bf16x8 pf = probs(s2_);
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[0], pf, o[0], 0, 0, 0);
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[1], pf, o[1], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (s2_ + 2 < 2 * KT) { va[0] = vfrag(s2_ + 2, 0); va[1] = vfrag(s2_ + 2, 1); }
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    const bf16x8 pf = probs(s2_ + 1);
-                    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[0], pf, o[0], 0, 0, 0);
-                    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[1], pf, o[1], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
-        // ---- x1 = x + O for this head's 64 columns (lane = query row, 4 consecutive columns per register quad)
-        bf16x4 x1b[2][4];
-        {
-            const bf16* xp = p.x + (row_base + q0 + l31) * d + h * 64 + 4 * hi;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const bf16x4 xv = *reinterpret_cast<const bf16x4*>(xp + ct * 32 + rq * 8);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bf16 r = (bf16)((float)xv[e] + o[ct][rq * 4 + e] * inv);
-                        x1b[ct][rq][e] = r;
-                        const float rf = (float)r;
-                        s1 += rf; s2 = fmaf(rf, rf, s2);
-                    }
-                }
-        }
-        // logits: D[h'][query] += wd[h'][this head's 64 columns] . x1  (B operand straight from the values above)
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {
-            const int ct = sl >> 1, s = sl & 1;
-            union { bf16x8 v; bf16x4 q[2]; } bx;
-            bx.q[0] = x1b[ct][2 * s]; bx.q[1] = x1b[ct][2 * s + 1];
-            bf16x8 af = *reinterpret_cast<const bf16x8*>(WT + ((((h * 4 + sl) * 2 + hi) * 16 + (l31 & 15)) << 4));
-            if (l31 >= 16) af = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bx.v, D, 0, 0, 0);
-        }
-        // (x1 of this head is stored at the START of the next head -- see flush_x1 -- so that the per-head vmcnt(0) never waits for stores
-        // that were issued a moment ago)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) x1prev[ct][rq] = x1b[ct][rq];
-    }
-    flush_x1(H - 1);
-
-    // ---- LayerNorm-2 statistics of the stored rows, logits, probabilities
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    const float mean = s1 * inv_d;
-    const float rstd = __builtin_amdgcn_rsqf(fmaxf(fmaf(s2, inv_d, -mean * mean), 0.f) + kLnEps);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int hr = (r & 3) + 8 * (r >> 2) + 4 * hi;                 // the cross head this register holds (accumulator row order)
-        if (hr < H) {
-            const float dl = rstd * (D[r] - mean * W1[hr]) + BW[hr];
-            PT[l31 * 16 + hr] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-dl * 1.44269504088896340736f));
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // this wave's x1 stores are complete; its P table is written
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
-    // ---- second pass over the wave's 32 rows: x += p v_label + (1 - p) v_noise; statistics of the stored row for LayerNorm-3
-    float4 xr[2][NQ];
-    auto fetch_row = [&](int rr, float4 (&xv)[NQ]) {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) xv[j] = rs_load4(p.x + (row_base + q0 + rr) * d + j * 256 + 4 * lane);
-    };
-    fetch_row(0, xr[0]);
-    fetch_row(1, xr[1]);
-#pragma unroll 1
-    for (int rr = 0; rr < 32; rr += 2) {
-        f32x4 v[2][NQ];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) v[u][j] = f32x4{xr[u][j].x, xr[u][j].y, xr[u][j].z, xr[u][j].w};
-        if (rr + 2 < 32) { fetch_row(rr + 2, xr[0]); fetch_row(rr + 3, xr[1]); }
-        float mean3[2], rstd3[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const int n = j * 256 + 4 * lane;
-                const float pl = PT[(rr + u) * 16 + 4 * j + (lane >> 4)];       // features of group j in lane l belong to head 4 j + (l >> 4)
-                const f32x4 a = *reinterpret_cast<const f32x4*>(vn + n);
-                const f32x4 dd = *reinterpret_cast<const f32x4*>(vdiff + n);
-                const f32x4 pl4 = {pl, pl, pl, pl};
-                v[u][j] += __builtin_elementwise_fma(pl4, dd, a);
-                rs_store4(p.x + (row_base + q0 + rr + u) * d + n, make_float4(v[u][j][0], v[u][j][1], v[u][j][2], v[u][j][3]));
-#pragma unroll
-                for (int e2 = 0; e2 < 4; ++e2) v[u][j][e2] = rs_round(v[u][j][e2]);
-                s4 += v[u][j];
-            }
-            mean3[u] = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_d;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                v[u][j] -= mean3[u];
-                q4 = __builtin_elementwise_fma(v[u][j], v[u][j], q4);
-            }
-            rstd3[u] = __builtin_amdgcn_rsqf(fmaf(wave_sum((q4[0] + q4[1]) + (q4[2] + q4[3])), inv_d, kLnEps));
-        }
-        if (lane == 0) {
-            p.ln3_stats[row_base + q0 + rr] = make_float2(mean3[0], rstd3[0]);
-            p.ln3_stats[row_base + q0 + rr + 1] = make_float2(mean3[1], rstd3[1]);
-        }
-    }
-}
-
 template <int KT, int NW, int QT, bool PIPE>
 void launch_attn1(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
     constexpr int KC = KT * 32;
@@ -1127,8 +772,7 @@ void launch_attn1(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok
 template <int KT, int NW>
 void launch_kt(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
     constexpr int KC = KT * 32;
-    static const bool dbuf_on = !(getenv("TLD_ATTN_DBUF") && atoi(getenv("TLD_ATTN_DBUF")) == 0);     // A/B knob
-    const int nbuf = (ntok > KC && dbuf_on && 2 * (KC * 128 + 64 * (KC * 2 + 8)) <= 160 * 1024) ? 2 : 1;
+    const int nbuf = (ntok > KC && 2 * (KC * 128 + 64 * (KC * 2 + 8)) <= 160 * 1024) ? 2 : 1;       // (the engine's shapes are all single-chunk here: ntok == KC)
     const int lds = nbuf * (KC * 128 + 64 * (KC * 2 + 8));
     static PerDeviceMax attr_lds;
     if (attr_lds.raise(lds))
@@ -1148,51 +792,13 @@ void launch_attn2(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok
 
 }  // namespace
 
-bool attn_cross_supported(int ntok, int d) {
-#ifdef TLD_RESID_BF16
-    // OFF by default: measured 111 us per layer against 45 + 45 us for attn1 + cross_row (profiles/r03_attn_cross_fused_ab.txt) -- a wave
-    // walks the 12 heads alone on its SIMD (147 KB of LDS: one workgroup per CU), and with 128 samples the two workgroups of a sample
-    // each stage the sample's K / V^T, so the HBM bytes do not go down.  TLD_FUSE_ATTN_CROSS=1 selects it (parity-tested).
-    static const bool on = getenv("TLD_FUSE_ATTN_CROSS") && atoi(getenv("TLD_FUSE_ATTN_CROSS")) != 0;
-    return on && ntok == 256 && (d == 256 || d == 512 || d == 768);
-#else
-    (void)ntok; (void)d;
-    return false;
-#endif
-}
-
-void launch_attn_cross(const AttnCrossParams& p, hipStream_t s) {
-#ifdef TLD_RESID_BF16
-#define TLD_AC_LAUNCH(NQ)                                                                                                       \
-    do {                                                                                                                        \
-        constexpr int lds = ac_lds(NQ * 4, NQ * 256);                                                                           \
-        static PerDeviceOnce once;                                                                                              \
-        if (once.first()) hipFuncSetAttribute(reinterpret_cast<const void*>(attn_cross_kernel<NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL(attn_cross_kernel<NQ>, dim3(2, 1, p.batch), dim3(256), lds, s, p);                                    \
-    } while (0)
-    if (p.d == 768) TLD_AC_LAUNCH(3);
-    else if (p.d == 512) TLD_AC_LAUNCH(2);
-    else TLD_AC_LAUNCH(1);
-#undef TLD_AC_LAUNCH
-#else
-    (void)p; (void)s;
-#endif
-}
-
 void launch_attention(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads,
                       hipStream_t s) {
-    // 256-key chunks staged once per workgroup of 8 waves (256 query rows).  Measured alternative: 4-wave
-    // workgroups, two per CU (staging overlapped with compute) -- 88 us vs 60 us per layer at C1, the K/V
-    // chunk is then staged twice per head and the extra L2->LDS traffic costs more than the overlap buys.
-    static const bool one_wg = getenv("TLD_ATTN_8W") && atoi(getenv("TLD_ATTN_8W")) != 0;     // A/B knob: single 8-wave workgroup per CU
-    static const bool attn2_on = !(getenv("TLD_ATTN2") && atoi(getenv("TLD_ATTN2")) == 0);            // A/B knob: attn_kernel<8, 8> for >= 512 tokens
-    static const bool pipe = !(getenv("TLD_ATTN_PIPE") && atoi(getenv("TLD_ATTN_PIPE")) == 0);        // A/B knob: compiler-scheduled fragment reads
-    if (ntok == 256 && !one_wg) {
-        if (pipe) launch_attn1<8, 4, 2, true>(qk, vt, att, batch, ntok, heads, s);
-        else launch_attn1<8, 4, 2, false>(qk, vt, att, batch, ntok, heads, s);
-    }
-    else if (ntok % 256 == 0 && ntok >= 512 && attn2_on) launch_attn2(qk, vt, att, batch, ntok, heads, s);
-    else if (ntok % 256 == 0) launch_kt<8, 8>(qk, vt, att, batch, ntok, heads, s);
+    // 256 tokens: two unsynchronised 4-wave workgroups per CU, each staging its (sample, head)'s K / V^T once (attn1_kernel; the single
+    // 8-wave workgroup it replaced took 60 us against 44 at C1).  512+ tokens: the chunked two-query-tile kernel (attn2_kernel).
+    // (At the C1 shape the inference engine no longer comes here: its self-attention runs in the QKV GEMM's epilogue, EPI_QKV_ATTN.)
+    if (ntok == 256) launch_attn1<8, 4, 2, true>(qk, vt, att, batch, ntok, heads, s);
+    else if (ntok % 256 == 0) launch_attn2(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 128) launch_kt<4, 4>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 64) launch_kt<2, 2>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 32) launch_kt<1, 1>(qk, vt, att, batch, ntok, heads, s);

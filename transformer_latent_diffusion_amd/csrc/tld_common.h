@@ -159,6 +159,15 @@ __device__ __forceinline__ float4 rs_load4(const resid_t* p) {
     return *reinterpret_cast<const float4*>(p);
 #endif
 }
+// four residual values as they sit in memory (prefetch registers: half the space of float4 in the bf16 build) and their fp32 view
+#ifdef TLD_RESID_BF16
+typedef bf16x4 resid4_t;
+__device__ __forceinline__ float4 rs_widen4(resid4_t v) { return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]); }
+#else
+typedef float4 resid4_t;
+__device__ __forceinline__ float4 rs_widen4(resid4_t v) { return v; }
+#endif
+__device__ __forceinline__ resid4_t rs_raw4(const resid_t* p) { return *reinterpret_cast<const resid4_t*>(p); }
 __device__ __forceinline__ void rs_store4(resid_t* p, float4 v) {
 #ifdef TLD_RESID_BF16
     bf16x4 o; o[0] = (bf16)v.x; o[1] = (bf16)v.y; o[2] = (bf16)v.z; o[3] = (bf16)v.w;
@@ -221,9 +230,13 @@ enum GemmEpilogue {
     EPI_BIAS_BF16 = 2,   // bf16(C + bias[n]) -> [M,N]           (MLP up projection)
     EPI_BIAS_RESID = 3,  // x[m,n] += C + bias[n] (resid_t)      (MLP down projection)
     EPI_QKV_LN = 5,      // EPI_QKV with LayerNorm-1 folded in (A = raw residual stream, see GemmParams::ln_stats)
-    EPI_UP_DWCONV = 4,   // bf16(C + bias) -> depthwise 3x3 + bias + GELU over the tile's 16x16 image -> [M,N]
-                         // (MLP up projection fused with the depthwise conv; needs ntok == 256, BN == 256)
-    EPI_UP_DWCONV2 = 6,  // the same fusion on a token-pair image with packed-bf16 taps (v_dot2c_f32_bf16), see tld_gemm.hip
+    EPI_UP_DWCONV2 = 6,  // bf16(C + bias) -> depthwise 3x3 + bias + GELU over the tile's 16x16 image -> [M,N]  (MLP up projection fused with
+                         // the depthwise conv: token-pair image in LDS, packed-bf16 taps on v_dot2c_f32_bf16; needs ntok == 256, BN == 256.
+                         // Value 4 was the first form of this epilogue, retired in round 4.)
+    EPI_QKV_ATTN = 7,    // QKV GEMM (LayerNorm-1 folded in) + the head's whole self-attention in the epilogue: W rows are permuted to
+                         // [head][q_h | k_h | v_h] so that a 256 x 192 tile = everything (sample, head) needs; q, k, v^T go from the
+                         // accumulators to LDS, softmax(q k^T / 8) v runs there, and only att[256 x 64] is written (out_bf16, ldo = d).
+                         // Needs ntok == 256, N = 3 d = heads x 192, K % 128 == 0.  (tld/transformer_blocks.py:51-59 + 24-48)
 };
 
 // Launch-side caches are PER DEVICE: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current device only, and engines on
@@ -288,8 +301,7 @@ struct GemmParams {
     bf16* vt;                     // EPI_QKV
     int ntok, d;                  // EPI_QKV
     const float* bias;            // EPI_BIAS_*
-    const float* dw_w9c;          // EPI_UP_DWCONV: HALVED depthwise weights [9][N]  (the epilogue's GELU takes x / 2)
-    const float* dw_b;            // EPI_UP_DWCONV: HALVED depthwise bias [N]
+    const float* dw_b;            // EPI_UP_DWCONV2: HALVED depthwise bias [N]  (the epilogue's GELU takes x / 2)
     const uint32_t* dw_wpk;       // EPI_UP_DWCONV2: HALVED depthwise taps as packed bf16 pairs [3 window rows][4 kinds][N]:
                                   //   kinds (lo, hi): (0, w0), (w1, w2) for even output columns; (w0, w1), (w2, 0) for odd ones
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
@@ -302,7 +314,7 @@ struct GemmParams {
     const float2* ln_stats;       // EPI_QKV_LN: [M][kLnSlots] partials of the A rows
     int ln_slots;                 // EPI_QKV_LN: slots to sum per row (even, <= kLnSlots)
     const float* ln_b1;           // EPI_QKV_LN: [N] beta1 . Wqkv^T   (ln_c1 below holds the column sums)
-    // EPI_UP_DWCONV with LayerNorm-3 folded in: A is the raw bf16 residual stream, W = bf16(gamma3 (.) Wup),
+    // EPI_UP_DWCONV2 / EPI_BIAS_BF16 with LayerNorm-3 folded in: A is the raw bf16 residual stream, W = bf16(gamma3 (.) Wup),
     // bias = up_b + beta3 . Wup^T, and the image write applies  rstd_m (acc - mean_m c1[n]) + bias[n]
     const float2* row_stats;      // [M] (mean, rstd) per row; null: A is already normalized
     const float* ln_c1;           // [N] column sums of the gamma-scaled bf16 weights
@@ -333,10 +345,8 @@ struct GemmParams {
     // group, gn_hw pixels per sample.  Requires gn_hw % 256 == 0 (a tile never straddles samples), N % 128 == 0, gn_cpg % 4 == 0.
     float2* gn_partial;
     int gn_groups, gn_cpg, gn_hw;
-    unsigned long long* trace;    // optional s_memtime trace buffer (tools/gemm_bench.py, TLD_GEMM_TRACE=1)
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0
     int half_tail;                // ring K loop: split the tiles of a partly filled last round by ROWS between two workgroups (set by the launcher)
-    int dbg_no_dma;               // experiment knob (tools/gemm_bench.py, TLD_GEMM_DBG=2): no tile DMA inside the K loop
     int dbg_epi;                  // experiment knob, builds with -DTLD_DBG_EPI only (TLD_EPI_DBG bit mask, see tld_gemm.hip)
 };
 
@@ -411,27 +421,9 @@ struct CrossRowParams {
     uint8_t* xn3_s8;              //   ... and its E8M0 block scales [d/128][M][4]
     float* sa_out;                // optional debug dump of x + att  [M,d]
     int batch, ntok, d, heads;
-    int dbg;                      // attribution knob (TLD_CROSS_DBG): 1 = no logit dot products, 2 = no per-workgroup table fill either (wrong results)
 };
 void launch_cross_row(const CrossRowParams& p, hipStream_t s);
 bool cross_row_supports_ln3_stats(int d);
-
-// Self-attention + residual add + cross-attention + residual add + LayerNorm-3 statistics in ONE kernel (256-token grids, bf16 residual
-// stream, LayerNorm-3 folded into the up-projection): see attn_cross_kernel in tld_attn.hip.  Same tables as CrossRowParams.
-struct AttnCrossParams {
-    const bf16* qk;               // [M, 2d] q | k
-    const bf16* vt;               // [B, H, 64, N]
-    resid_t* x;                   // [M, d] residual stream, updated in place
-    const float* wq;              // [T, H, d]
-    const float* bwq;             // [T, H]
-    const float* v; int v_ld;     // [T, v_ld]
-    const int* noise_row;         // [B]
-    const int* label_row;         // [B]
-    float2* ln3_stats;            // [M] (mean, rstd) of the stored new residual rows
-    int batch, ntok, d, heads;
-};
-bool attn_cross_supported(int ntok, int d);
-void launch_attn_cross(const AttnCrossParams& p, hipStream_t s);
 
 struct TailParams {
     const resid_t* tok;           // [B*N, d]

@@ -74,6 +74,8 @@ struct Layer {
     bf16 *qkv_w = nullptr, *up_w = nullptr, *down_w = nullptr;
     bf16 *qkv_wf = nullptr;                               // bf16(gamma1 (.) Wqkv): LayerNorm-1 folded into the QKV GEMM
     float *qkv_c1 = nullptr, *qkv_b1 = nullptr;           // [3d] column sums of qkv_wf; beta1 . Wqkv^T
+    bf16 *qkv_wp = nullptr;                               // qkv_wf with its rows permuted to [head][q_h | k_h | v_h] (fused QKV -> attention kernel)
+    float *qkv_c1p = nullptr, *qkv_b1p = nullptr;         // the same permutation of qkv_c1 / qkv_b1
     float *up_b = nullptr, *dw_w9c = nullptr, *dw_b = nullptr, *down_b = nullptr;
     float *dw_w9c_half = nullptr, *dw_b_half = nullptr;   // 0.5 x (exact): operands of the fused up-projection epilogue
     uint32_t* dw_wpk = nullptr;                           // the halved taps as packed bf16 pairs [3][4][hid] (EPI_UP_DWCONV2)
@@ -95,7 +97,6 @@ struct tld_engine {
     int d = 0, L = 0, H = 0, ntok = 0, grid = 0, pd = 0, hid = 0, img = 0, ne = 0, text = 0;
     bool finalized = false;
     bool fuse_dwconv = true;            // TLD_FUSE_DWCONV=0 selects the two-kernel path (A/B testing)
-    bool updw_v2 = true;                // TLD_UPDW_V2=0: first form of the fused depthwise epilogue (fp32 taps, A/B testing)
     bool fp8 = false;                   // QKV / MLP GEMMs on MX-fp8 operands (BASELINE config C4); set before finalize
     bool fp8_fused = true;              // TLD_FP8_FUSED=0: separate quantisation passes instead of quantising producers (A/B testing)
     uint8_t *a8 = nullptr, *as8 = nullptr;   // fp8 mode: quantised A operand [M, hid] and its block scales [hid/128][M][4]
@@ -117,6 +118,7 @@ struct tld_engine {
     resid_t* x_half = nullptr;         // patch embedding of the un-doubled batch (CFG layer-0 sharing)
     bool share_l0 = true;              // TLD_SHARE_L0=0 disables (A/B testing)
     bool fold_ln1 = true;              // TLD_FOLD_LN1=0: separate LayerNorm-1 kernel (A/B testing)
+    bool fuse_qkv_attn = true;         // 256-token grids with the LayerNorm-1 fold: QKV GEMM + self-attention as ONE kernel per (sample, head) (TLD_FUSE_QKV_ATTN=0: two kernels)
     float2* ln_stats = nullptr;        // [M][kLnSlots] row partial sums of the residual stream (embed / down GEMM -> QKV GEMM)
     bool fold_ln3 = true;              // TLD_FOLD_LN3=0: cross_row writes LN3(x) and the up-projection reads it (A/B testing)
     float2* row_stats = nullptr;       // [M] (mean, rstd) of the residual rows, cross_row -> up-projection epilogue
@@ -315,7 +317,17 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             if (fuse8 && layernorm_mx8_supported(d)) launch_layernorm_mx8(half ? xe : e->x, Ly.n1_w, Ly.n1_b, e->a8, e->as8, Ml, d, s);
             else launch_layernorm_bf16(half ? xe : e->x, Ly.n1_w, Ly.n1_b, e->xn, Ml, d, s);
         }
-        {   // q|k, v^T = LN1(x) Wqkv^T
+        // 256-token grids with the LayerNorm-1 fold: the QKV projection and the whole self-attention of a (sample, head) are one 256 x 192
+        // GEMM tile + epilogue; q | k, v^T never reach HBM and `att` is written directly.  (debug stage dumps and fp8 keep the two kernels)
+        const bool fused_qa = e->fuse_qkv_attn && fold1 && !e->fp8;
+        if (fused_qa) {
+            ProfScope ps(e, KC_GEMM_QKV, s);
+            GemmParams g{};
+            g.A = half ? xe : e->x; g.lda = d; g.W = Ly.qkv_wp; g.ldw = d; g.M = Ml; g.N = 3 * d; g.K = d;
+            g.out_bf16 = e->att; g.ldo = d; g.ntok = e->ntok; g.d = d;
+            g.ln_stats = e->ln_stats; g.ln_slots = l == 0 ? 2 : ln_slots; g.ln_c1 = Ly.qkv_c1p; g.ln_b1 = Ly.qkv_b1p;
+            launch_gemm(g, EPI_QKV_ATTN, s);
+        } else {   // q|k, v^T = LN1(x) Wqkv^T
             ProfScope ps(e, KC_GEMM_QKV, s);
             GemmParams g{};
             g.A = e->xn; g.lda = d; g.W = Ly.qkv_w; g.ldw = d; g.M = Ml; g.N = 3 * d; g.K = d;
@@ -333,21 +345,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
 #endif
             launch_gemm(g, fold1 ? EPI_QKV_LN : EPI_QKV, s);
         }
-        // 256-token grids, bf16 stream, LayerNorm-3 folded: self-attention, both residual adds, the cross-attention sub-block and the
-        // LayerNorm-3 statistics are ONE kernel (attn_cross_kernel); `att` is never materialised.  Block 0 under CFG sharing (its
-        // attention runs on the un-doubled batch and fans out), the fp8 producers and the debug stage dumps keep the two-kernel path.
-        const bool fused_ac = attn_cross_supported(e->ntok, d) && e->fold_ln3 && !half && !e->debug && !e->fp8;
-        if (fused_ac) {
-            ProfScope ps(e, KC_ATTN, s);
-            AttnCrossParams ap{};
-            ap.qk = e->qk; ap.vt = e->vt; ap.x = e->x;
-            ap.wq = e->c_wq + (size_t)l * e->cond_cap * e->H * d;
-            ap.bwq = e->c_bwq + (size_t)l * e->cond_cap * e->H;
-            ap.v = e->c_kv + (size_t)l * e->cond_cap * 2 * d + d; ap.v_ld = 2 * d;
-            ap.noise_row = noise_row; ap.label_row = label_row; ap.ln3_stats = e->row_stats;
-            ap.batch = batch; ap.ntok = e->ntok; ap.d = d; ap.heads = e->H;
-            launch_attn_cross(ap, s);
-        } else {
+        if (!fused_qa) {
             ProfScope ps(e, KC_ATTN, s);
             launch_attention(e->qk, e->vt, e->att, bl, e->ntok, e->H, s);
         }
@@ -360,7 +358,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
         // up-projection's epilogue and the pre-conv hidden never reaches HBM.  Other grids: separate kernels.
         const bool fuse_dw = e->fuse_dwconv && e->grid == 16 && e->hid % 256 == 0;
         const bool fold3 = e->fold_ln3;                 // LN3 applied in the up-projection's epilogue: cross_row writes row statistics, not xn
-        if (!fused_ac) {   // x += att; x += CA(LN2 x, y); xn = LN3(x)
+        {   // x += att; x += CA(LN2 x, y); xn = LN3(x) (or its row statistics)
             ProfScope ps(e, KC_CROSS, s);
             CrossRowParams cp{};
             cp.x = e->x; cp.att = e->att;
@@ -382,14 +380,14 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             ProfScope ps(e, KC_GEMM_UP, s);
             GemmParams g{};
             g.A = e->xn; g.lda = d; g.W = Ly.up_w; g.ldw = d; g.M = M; g.N = e->hid; g.K = d;
-            g.out_bf16 = e->hid2; g.ldo = e->hid; g.bias = Ly.up_b; g.dw_w9c = Ly.dw_w9c_half; g.dw_b = Ly.dw_b_half;
+            g.out_bf16 = e->hid2; g.ldo = e->hid; g.bias = Ly.up_b; g.dw_b = Ly.dw_b_half;
             g.dw_wpk = Ly.dw_wpk;
 #ifdef TLD_RESID_BF16
             if (fold3) {    // LN3 inside the epilogue: raw residual rows x gamma-scaled weights, statistics from cross_row
                 g.A = e->x; g.W = Ly.up_wf; g.bias = Ly.up_b1; g.ln_c1 = Ly.up_c1; g.row_stats = e->row_stats;
             }
 #endif
-            launch_gemm(g, e->updw_v2 ? EPI_UP_DWCONV2 : EPI_UP_DWCONV, s);
+            launch_gemm(g, EPI_UP_DWCONV2, s);
         } else {
             {   // hid1 = xn Wup^T + b
                 ProfScope ps(e, KC_GEMM_UP, s);
@@ -500,7 +498,6 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     e->layers.resize(e->L);
     if (const char* fd = getenv("TLD_FUSE_DWCONV")) e->fuse_dwconv = atoi(fd) != 0;
     if (const char* sl = getenv("TLD_SHARE_L0")) e->share_l0 = atoi(sl) != 0;
-    if (const char* v2 = getenv("TLD_UPDW_V2")) e->updw_v2 = atoi(v2) != 0;
     if (const char* f8 = getenv("TLD_FP8_FUSED")) e->fp8_fused = atoi(f8) != 0;
     if (const char* fl = getenv("TLD_FOLD_LN3")) e->fold_ln3 = atoi(fl) != 0;
     if (const char* fl = getenv("TLD_FOLD_LN1")) e->fold_ln1 = atoi(fl) != 0;
@@ -514,6 +511,10 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     // needs the statistics-writing row kernel; both up-projection epilogues (fused depthwise at 16 x 16 tokens, plain
     // bias + bf16 otherwise) apply the fold
     e->fold_ln3 = e->fold_ln3 && e->hid % 256 == 0 && cross_row_supports_ln3_stats(e->d);
+    // fused QKV -> attention: one 256 x 192 tile per (sample, head) needs 256-token samples, the LayerNorm-1 fold (the kernel reads the raw
+    // residual stream) and an even number of 64-wide K-steps (its LDS map relies on which stage a tile consumes last)
+    if (const char* fq = getenv("TLD_FUSE_QKV_ATTN")) e->fuse_qkv_attn = atoi(fq) != 0;
+    e->fuse_qkv_attn = e->fuse_qkv_attn && e->fold_ln1 && ntok == 256 && e->d % 128 == 0;
     *out = e;
     return TLD_OK;
 }
@@ -622,6 +623,24 @@ int tld_engine_finalize_weights(tld_engine* e) {
             HIP_TRY(hipMemcpy(Ly.qkv_c1, c1.data(), c1.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(Ly.qkv_b1, b1.data(), b1.size() * 4, hipMemcpyHostToDevice));
             e->weight_bytes += (int64_t)wf.size() * 2 + (int64_t)c1.size() * 8;
+            if (e->fuse_qkv_attn) {     // rows [q; k; v] x [head][64]  ->  [head][q_h | k_h | v_h]: tile-column h of the fused kernel is head h
+                std::vector<uint16_t> wp(wf.size());
+                std::vector<float> c1p(c1.size()), b1p(b1.size());
+                for (int64_t h = 0; h < e->H; ++h)
+                    for (int part = 0; part < 3; ++part)
+                        for (int64_t c = 0; c < 64; ++c) {
+                            const int64_t src = part * d + h * 64 + c, dst = h * 192 + part * 64 + c;
+                            memcpy(&wp[(size_t)(dst * d)], &wf[(size_t)(src * d)], (size_t)d * 2);
+                            c1p[(size_t)dst] = c1[(size_t)src]; b1p[(size_t)dst] = b1[(size_t)src];
+                        }
+                if (int rc = dev_alloc(e, &Ly.qkv_wp, wp.size())) return rc;
+                if (int rc = dev_alloc(e, &Ly.qkv_c1p, c1p.size() + 64)) return rc;      // (+64: the side-table DMA of the last head reads a 256-column window)
+                if (int rc = dev_alloc(e, &Ly.qkv_b1p, b1p.size() + 64)) return rc;
+                HIP_TRY(hipMemcpy(Ly.qkv_wp, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(Ly.qkv_c1p, c1p.data(), c1p.size() * 4, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemcpy(Ly.qkv_b1p, b1p.data(), b1p.size() * 4, hipMemcpyHostToDevice));
+                e->weight_bytes += (int64_t)wp.size() * 2 + (int64_t)c1p.size() * 8;
+            }
         }
         if (e->fp8) {
             struct Q { const char* key; int64_t rows, K; uint8_t** w; uint8_t** sc; };
@@ -896,10 +915,9 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     g.A = A; g.lda = K; g.W = W; g.ldw = K; g.M = M; g.N = N; g.K = K;
     g.c_f32 = res; g.ldc = N; g.out_bf16 = out; g.ldo = epilogue == EPI_QKV ? 2 * (N / 3) : N; g.vt = vt;
     g.ntok = ntok > 0 ? ntok : 1; g.d = N / 3; g.bias = bias; g.resid = reinterpret_cast<resid_t*>(res); g.ldr = N;
-    g.dbg_no_dma = (getenv("TLD_GEMM_DBG") && atoi(getenv("TLD_GEMM_DBG")) == 2) ? 1 : 0;
     g.dbg_epi = getenv("TLD_EPI_DBG") ? atoi(getenv("TLD_EPI_DBG")) : 0;
     float *dww = nullptr;
-    if (epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2) {
+    if (epilogue == EPI_UP_DWCONV2) {
         if (M % 256 || N % 256) return fail(TLD_ERR_INVALID, "fused depthwise epilogue needs M, N multiples of 256");
         HIP_TRY(hipMalloc(&dww, (size_t)N * 22 * 4));
         std::vector<float> hw((size_t)N * 22);
@@ -907,17 +925,10 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
         uint32_t* pk = reinterpret_cast<uint32_t*>(hw.data() + (size_t)N * 10);
         for (size_t i = 0; i < (size_t)N * 12; ++i) pk[i] = 0x3d803d00u + (uint32_t)(i % 5) * 0x00010001u;     // small bf16 pairs
         HIP_TRY(hipMemcpy(dww, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
-        g.dw_w9c = dww; g.dw_b = dww + (size_t)N * 9; g.dw_wpk = reinterpret_cast<const uint32_t*>(dww + (size_t)N * 10);
+        g.dw_b = dww + (size_t)N * 9; g.dw_wpk = reinterpret_cast<const uint32_t*>(dww + (size_t)N * 10);
     }
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-    unsigned long long* trace = nullptr;
-    constexpr size_t kTraceWords = 8 * 16 * 16;
-    if (getenv("TLD_GEMM_TRACE")) {
-        HIP_TRY(hipMalloc(&trace, kTraceWords * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(trace, 0, kTraceWords * sizeof(unsigned long long)));
-        g.trace = trace;
-    }
     auto run = [&]() { launch_gemm(g, epilogue, nullptr); };
     for (int i = 0; i < 3; ++i) run();
     HIP_TRY(hipEventRecord(a, nullptr));
@@ -927,32 +938,6 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, a, b));
     *avg_ms = ms / iters;
-    if (trace) {
-        std::vector<unsigned long long> h(kTraceWords);
-        HIP_TRY(hipMemcpy(h.data(), trace, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        const bool stag = h[3] != 0 && h[8] != 0;          // the staggered K loop writes 16 stamps per K-step, the plain one 6
-        unsigned long long t00 = ~0ull;
-        for (size_t i = 0; i < h.size(); ++i) if (h[i] && h[i] < t00) t00 = h[i];
-        if (stag) {
-            printf("# s_memtime trace (staggered K loop), workgroup 0, first tile; per wave and K-step, for each k-slice: R start | frags in "
-                   "registers | past barrier 1 | MFMAs issued  (cycles since the first stamp)\n");
-            for (int w = 0; w < 8; ++w)
-                for (int k = 0; k < 12; ++k) {
-                    printf("w%d k%2d:", w, k);
-                    for (int sl = 0; sl < 16; ++sl) printf(" %6lld%s", (long long)(h[(w * 16 + k) * 16 + sl] - t00), (sl & 3) == 3 ? " |" : "");
-                    printf("\n");
-                }
-        } else {
-            printf("# s_memtime trace, workgroup 0, first tile: per wave, per K-step: top | +vmcnt | +barrier | +grp0 | +grp3 issued | +lgkm  (cycles since the first stamp)\n");
-            for (int w = 0; w < 8; ++w)
-                for (int k = 0; k < 12; ++k) {
-                    printf("w%d k%2d:", w, k);
-                    for (int sl = 0; sl < 6; ++sl) printf(" %7lld", (long long)(h[(w * 16 + k) * 6 + sl] - t00));
-                    printf("\n");
-                }
-        }
-        hipFree(trace);
-    }
     hipEventDestroy(a); hipEventDestroy(b);
     hipFree(A); hipFree(W); hipFree(out); hipFree(vt); hipFree(bias); hipFree(res); hipFree(dww);
     HIP_TRY(hipGetLastError());

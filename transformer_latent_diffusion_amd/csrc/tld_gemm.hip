@@ -6,6 +6,7 @@
 // One persistent workgroup per CU (8 waves) walks a static list of 256-row tiles; see the comment above
 // gemm256p_kernel for the pipeline and DESIGN.md 4.1 for the measurements that shaped it.
 #include "tld_common.h"
+#include "tld_attn_core.h"
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -19,20 +20,8 @@
 #define TLD_EPI_BIT(b) false
 #endif
 
-#ifndef TLD_KLOOP_STAGGER
-#define TLD_KLOOP_STAGGER 1   // staggered 8-interval K-step (see gemm256p_kernel); -DTLD_KLOOP_STAGGER=0 builds the one-barrier form (A/B)
-#endif
-
-#ifndef TLD_KLOOP_NS
-#define TLD_KLOOP_NS 1        // k-slices per barrier interval of the staggered K loop (1 or 2); the 384-wide tile always uses 1
-#endif
-
 #ifndef TLD_KLOOP_RING
-#define TLD_KLOOP_RING 1      // counted-vmcnt half-tile ring K loop for 256 x 256 tiles (see kloop_ring); 0 = never instantiate it.  TLD_GEMM_RING=0 in the environment keeps the two-stage loop at run time (same-box A/B)
-#endif
-
-#ifndef TLD_GLDS_AUX
-#define TLD_GLDS_AUX 0      // cache-policy bits of the tile DMA (experiment knob: 2 = nt; measured slower)
+#define TLD_KLOOP_RING 1      // counted-vmcnt half-tile ring K loop for 256 x 256 tiles (see kloop_ring); 0 = never instantiate it (the two-stage staggered loop everywhere)
 #endif
 
 namespace tld {
@@ -93,11 +82,7 @@ struct G256P : G256<BN> {
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
     // EPI_QKV_LN: behind the two stages, the tile's raw row partial sums (256 x 64 B, DMA) and the reduced (mean, rstd)
     static constexpr int LN_RAW = LDS_BYTES, LN_ST = LN_RAW + 256 * 8 * kLnSlots, LN_CB = LN_ST + 256 * 8, QKVLN_LDS = LN_CB + 2048;   // + c1 | b1 of the tile's columns
-    static constexpr int IMG_PITCH = 520;            // fused depthwise epilogue: bytes per token row of the LDS image (512 + 8)
-    static constexpr int IMG_BYTES = 256 * IMG_PITCH;
-    static constexpr int ROWSTAT_OFF = IMG_BYTES;    // folded LayerNorm-3: the tile's 256 (mean, rstd) pairs, behind the image
-    static constexpr int UPDW_LDS = IMG_BYTES + 256 * 8;
-    // second form of the fused depthwise epilogue (EPI_UP_DWCONV2): image of TOKEN PAIRS, one dword = (token 2p, token 2p+1)
+    // fused depthwise epilogue (EPI_UP_DWCONV2): image of TOKEN PAIRS, one dword = (token 2p, token 2p+1)
     // of one channel, [128 pairs][256 channels] with a 1-KiB pitch (no padding needed: every access of a wave is a
     // contiguous run), an all-zero pair-row for the rows above / below the image, then the (mean, rstd) pairs
     static constexpr int IMG2_PITCH = 1024, IMG2_BYTES = 128 * IMG2_PITCH;
@@ -108,6 +93,10 @@ struct G256P : G256<BN> {
     static constexpr int PLAINRS_OFF = LDS_BYTES;    // EPI_BIAS_BF16 with folded LayerNorm-3: the tile's 256 (mean, rstd) pairs
     static constexpr int PLAINLN_LDS = LDS_BYTES + 256 * 8;
     static constexpr int SCRATCH = 4608;             // per-wave epilogue scratch (8 x 4608 <= one stage)
+    // EPI_QKV_ATTN (BN = 192): stage 0 keeps receiving the next tile's first K-step while the epilogue runs; the head's K, V^T and Q
+    // images live behind it (stage 1, which a tile of an even number of K-steps consumes last, the LayerNorm side tables -- dead once the
+    // accumulators are normalised -- and the rest of the CU's 160 KiB)
+    static constexpr int AT_K = STAGE_BYTES, AT_V = AT_K + 256 * 128, AT_Q = AT_V + 64 * kAttnVPitch, ATTN_LDS = AT_Q + 256 * 128;
 };
 
 // F8 = true: both operands are OCP e4m3 bytes with MX block scales (one E8M0 byte per 32 K-elements), multiplied by
@@ -120,14 +109,15 @@ struct G256P : G256<BN> {
 template <int BN, int EPI, bool F8 = false, bool CONV = false, bool RING = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks) {
     using G = G256P<BN>;
-    static_assert(!RING || (BN == 256 && !F8 && TLD_KLOOP_STAGGER), "the half-tile ring exists for bf16 256 x 256 tiles");
+    static_assert(!RING || (BN == 256 && !F8), "the half-tile ring exists for bf16 256 x 256 tiles");
     using frag_t = std::conditional_t<F8, i32x8, bf16x8>;
     constexpr int ESZ = F8 ? 1 : 2;                                     // operand bytes per element
     constexpr int SC_OFF = G::LDS_BYTES;                                // F8: [stage][A scales 1 KiB | W scales 1 KiB] behind the stages
     static_assert(!F8 || (EPI == EPI_F32 || EPI == EPI_QKV || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID), "fp8 epilogues");
-    static_assert(!F8 || TLD_KLOOP_STAGGER, "the fp8 path exists in the staggered K loop only");
-    static_assert(!CONV || (!F8 && TLD_KLOOP_STAGGER && (EPI == EPI_F32 || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID)), "conv mode");
-    constexpr bool IS_QKV = EPI == EPI_QKV || EPI == EPI_QKV_LN, LN = EPI == EPI_QKV_LN;
+    static_assert(!CONV || (!F8 && (EPI == EPI_F32 || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID)), "conv mode");
+    constexpr bool IS_QKV = EPI == EPI_QKV || EPI == EPI_QKV_LN, LN = EPI == EPI_QKV_LN || EPI == EPI_QKV_ATTN;
+    static_assert(EPI != EPI_QKV_ATTN || (BN == 192 && !F8 && !CONV && !RING), "the fused attention epilogue is written for 256 x 192 tiles");
+    static_assert(EPI != EPI_QKV_ATTN || G::ATTN_LDS <= 160 * 1024, "LDS");
     static_assert(8 * G::SCRATCH <= G::STAGE_BYTES, "epilogue scratch must fit in one stage");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -267,11 +257,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     auto dma_piece = [&](int q2, int kbyte, char* st) {       // q2 < A_PIECES: A piece, else W piece; kbyte uniform
         if (q2 < G::A_PIECES) {
             const char* base = reinterpret_cast<const char*>(p.A) + (CONV ? conv_akb : kbyte);
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + voffA[q2]), (lptr_t)(st + (wid * G::A_PIECES + q2) * 1024), 16, 0, TLD_GLDS_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + voffA[q2]), (lptr_t)(st + (wid * G::A_PIECES + q2) * 1024), 16, 0, 0);
         } else {
             const char* base = reinterpret_cast<const char*>(p.W) + kbyte;
             __builtin_amdgcn_global_load_lds((gptr_t)(base + voffB[q2 - G::A_PIECES]),
-                                             (lptr_t)(st + G::A_BYTES + (wid * G::B_PIECES + (q2 - G::A_PIECES)) * 1024), 16, 0, TLD_GLDS_AUX);
+                                             (lptr_t)(st + G::A_BYTES + (wid * G::B_PIECES + (q2 - G::A_PIECES)) * 1024), 16, 0, 0);
         }
     };
     // F8: the block scales of one K-step -- 4 bytes per row, [K/128][rows][4] in memory, so a tile's strip is one
@@ -423,8 +413,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             char* dst = smem + slot * HT + wid * 2048;
             unsigned o0 = isA ? rvA[half * 2] : rvB[half * 2], o1 = isA ? rvA[half * 2 + 1] : rvB[half * 2 + 1];
             asm volatile("" : "+v"(o0), "+v"(o1));   // (keeps the zero-extension next to the load: saddr + 32-bit voffset form)
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + o0), (lptr_t)dst, 16, 0, TLD_GLDS_AUX);
-            __builtin_amdgcn_global_load_lds((gptr_t)(base + o1), (lptr_t)(dst + 1024), 16, 0, TLD_GLDS_AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + o0), (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + o1), (lptr_t)(dst + 1024), 16, 0, 0);
         }
     };
 
@@ -455,7 +445,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        frag_t a0[G::TM], b0[G::TN], a1[G::TM], b1[G::TN];
+        frag_t a0[G::TM], b0[G::TN];
         int sca[G::TM], scb[G::TN];                 // F8: this K-step's scale dwords of the lane's rows (already shifted by 8 hi)
         // per-tile side tables of the folded LayerNorms (row partial sums / (mean, rstd) pairs, column constants): DMA into LDS behind
         // the operand ring; issued in K-step 1 of the two-stage loop and at the tile start of the ring loop (every wave is then past
@@ -486,17 +476,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::PLAINRS_OFF + wid * 1024), 16, 0, 0);
                 }
             }
-            if constexpr (EPI == EPI_UP_DWCONV || EPI == EPI_UP_DWCONV2) {
-                constexpr int RS_OFF = EPI == EPI_UP_DWCONV ? G::ROWSTAT_OFF : G::ROWSTAT2_OFF;
+            if constexpr (EPI == EPI_UP_DWCONV2) {
+                constexpr int RS_OFF = G::ROWSTAT2_OFF;
                 if (p.row_stats && wid < 2) {
                     const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + RS_OFF + wid * 1024), 16, 0, 0);
                 }
-                if constexpr (EPI == EPI_UP_DWCONV2) {      // waves 2 / 3: c1 / bias of the tile's columns
-                    if (wid == 3 || (wid == 2 && p.row_stats)) {
-                        const float* src = (wid == 2 ? p.ln_c1 : p.bias) + n0 + lane * 4;
-                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::CB2_OFF + (wid - 2) * 1024), 16, 0, 0);
-                    }
+                if (wid == 3 || (wid == 2 && p.row_stats)) {      // waves 2 / 3: c1 / bias of the tile's columns
+                    const float* src = (wid == 2 ? p.ln_c1 : p.bias) + n0 + lane * 4;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::CB2_OFF + (wid - 2) * 1024), 16, 0, 0);
                 }
             }
         };
@@ -522,14 +510,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             // and the last MFMA group of a step is executed AFTER the next step's barrier, so the pipe has
             // register-resident work while the first fragments of the new tile are read from LDS.
             constexpr int NP = G::A_PIECES + G::B_PIECES;           // pieces per wave per K-step
-            // optional cycle trace (block 0, first 16 K-steps of its first tile): 6 stamps per step per wave
-            auto stamp = [&](int k, int slot) {
-#ifdef TLD_GEMM_TRACE_BUILD
-                if (p.trace && blockIdx.x == 0 && it == 0 && k < 16 && lane == 0)
-                    p.trace[(wid * 16 + k) * 6 + slot] = __builtin_amdgcn_s_memtime();
-#endif
-            };
-#if TLD_KLOOP_STAGGER
             {
             // Staggered form (the 8-phase idea of the gfx950 GEMM template): the two waves of every SIMD are w and w + 4;
             // waves 4-7 run ONE barrier interval behind waves 0-3, so in every interval one wave of each SIMD executes
@@ -547,7 +527,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 if (k == 1) aux_dma();
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
-                const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV && EPI != EPI_UP_DWCONV2);
+                const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV2);
                 const int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
                 if constexpr (CONV) {
                     if (k + 1 < nk) {
@@ -556,29 +536,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     conv_akb = ccb * (G::BK * 2);
                 }
                 if (k + 1 == nk && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
-                // NS k-slices per interval: 1 -> 8 intervals (barriers) per K-step with 8 (12) MFMAs each; 2 -> 4 intervals with
-                // 16 MFMAs each and two fragment sets (the 384-wide tile has no registers for a second set)
-                constexpr int NS = (BN == 384 || F8) ? 1 : TLD_KLOOP_NS;
-                constexpr int NI = (F8 ? 2 : 4) / NS;
-#ifndef TLD_KL_NDMA
-#define TLD_KL_NDMA 2       // experiment knob: R intervals of a bf16 K-step that carry tile DMA (1..3)
-#endif
-#ifndef TLD_KL_LGKM_LATE
-#define TLD_KL_LGKM_LATE 1  // fragments are waited for AFTER the barrier (the latency overlaps the barrier wait) except in the step's last interval, whose barrier frees the stage for DMA; 0 = always before (A/B: -1.5 % on the down projection)
-#endif
-                constexpr int NDMA = (NI == 4) ? TLD_KL_NDMA : (NI + 1) / 2;   // intervals that carry tile DMA
+                // one k-slice per interval: 8 intervals (barriers) per bf16 K-step with 6 / 8 / 12 MFMAs each (two k-slices per interval -- 4
+                // barriers, two fragment sets -- measured slower); the tile DMA of the next K-step rides in the first two R intervals
+                // (one: -1.7 %, three: +-0.3 %); fragments are waited for AFTER the barrier (the latency overlaps the barrier wait) except in the
+                // step's last interval, whose barrier frees the stage for DMA
+                constexpr int NI = F8 ? 2 : 4;
+                constexpr int NDMA = (NI == 4) ? 2 : 1;                       // intervals that carry tile DMA
 #pragma unroll
                 for (int h = 0; h < NI; ++h) {
-                    // ---- R interval   (optional s_memtime trace: 4 stamps per interval pair, see tld_debug_gemm_bench)
-                    auto stamp4 = [&](int slot) {
-#ifdef TLD_GEMM_TRACE_BUILD     // (-DTLD_GEMM_TRACE_BUILD only: even a not-taken stamp is an exec-mask branch per interval)
-                        if (p.trace && blockIdx.x == 0 && it == 0 && k < 16 && lane == 0)
-                            p.trace[(wid * 16 + k) * 16 + h * NS * 4 + slot] = __builtin_amdgcn_s_memtime();
-#endif
-                    };
-                    stamp4(0);
-                    load_frags(st, h * NS, a0, b0);
-                    if constexpr (NS == 2) load_frags(st, h * NS + 1, a1, b1);
+                    // ---- R interval
+                    load_frags(st, h, a0, b0);
                     if constexpr (F8) {
                         if (h == 0) {       // this K-step's block scales: 4 bytes per row; half hi uses bytes hi and 2 + hi
                             const char* sc = smem + SC_OFF + (g & 1) * 2048;
@@ -589,8 +556,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         }
                     }
                     // tile DMA of the next K-step: early in the step, so that every piece has >= 2 intervals to land before
-                    // the vmcnt(0) of the step's last interval (NS == 2: all in the first R interval; NS == 1: first two)
-                    if (h < NDMA && more && !p.dbg_no_dma) {
+                    // the vmcnt(0) of the step's last interval
+                    if (h < NDMA && more) {
                         constexpr int PER = (NP + NDMA - 1) / NDMA;
 #pragma unroll
                         for (int q2 = 0; q2 < NP; ++q2) {
@@ -603,23 +570,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         }
                     }
                     if (h == NI - 1) wait_vmcnt<0>();
-                    if (!TLD_KL_LGKM_LATE || h == NI - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    stamp4(1);
+                    if (h == NI - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
-                    stamp4(2);
                     // ---- M interval
                     __builtin_amdgcn_s_setprio(1);
                     if constexpr (F8) {
                         if (h == 0) mma(a0, b0, std::integral_constant<int, 0>{}); else mma(a0, b0, std::integral_constant<int, 1>{});
                     } else {
                         mma(a0, b0, std::integral_constant<int, 0>{});
-                        if constexpr (NS == 2) mma(a1, b1, std::integral_constant<int, 0>{});
                     }
                     __builtin_amdgcn_s_setprio(0);
                     if (h == NI - 1) wait_vmcnt<0>();
-                    stamp4(3);
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
@@ -627,57 +590,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             }
             if (!grp) __builtin_amdgcn_s_barrier();        // stagger out: both groups are past their last MFMA
             }
-#else
-            for (int k = 0; k < nk; ++k, ++g) {
-                stamp(k, 0);
-                wait_vmcnt<0>();                   // own DMA pieces of step g landed (and earlier epilogue stores)
-                stamp(k, 1);
-                __builtin_amdgcn_s_barrier();      // everybody's; stage (g+1)&1 (operands or epilogue scratch) is idle
-                stamp(k, 2);
-                if (k == 1) aux_dma();
-                const char* st = smem + (g & 1) * G::STAGE_BYTES;
-                char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
-                const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV && EPI != EPI_UP_DWCONV2);
-                const int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
-                if (k + 1 == nk && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
-                auto pieces = [&](int lo, int hi_) {
-                    if (!more || p.dbg_no_dma) return;
-#pragma unroll
-                    for (int q2 = 0; q2 < NP; ++q2) {
-                        if (q2 < lo || q2 >= hi_) continue;
-                        dma_piece(q2, pkb, nst);
-                    }
-                };
-                if constexpr (BN == 384) {
-                    // 192 accumulator registers per lane: fragments are single-buffered (the SIMD's other wave covers
-                    // the LDS latency), nothing is deferred across the barrier
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        load_frags(st, ks, a0, b0);
-                        pieces((ks * NP + 3) / 4, ((ks + 1) * NP + 3) / 4);
-                        mma(a0, b0, std::integral_constant<int, 0>{});
-                    }
-                    continue;
-                }
-                load_frags(st, 0, a0, b0);
-                if (k > 0) mma(a1, b1, std::integral_constant<int, 0>{});            // deferred: k-slice 3 of the previous step (fragments already in registers)
-                pieces(0, (NP + 3) / 4);
-                stamp(k, 3);
-                load_frags(st, 1, a1, b1);
-                pieces((NP + 3) / 4, (NP + 1) / 2);
-                mma(a0, b0, std::integral_constant<int, 0>{});
-                load_frags(st, 2, a0, b0);
-                pieces((NP + 1) / 2, (3 * NP + 3) / 4);
-                mma(a1, b1, std::integral_constant<int, 0>{});
-                load_frags(st, 3, a1, b1);
-                pieces((3 * NP + 3) / 4, NP);
-                mma(a0, b0, std::integral_constant<int, 0>{});
-                stamp(k, 4);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // k-slice 3 fragments are in registers before the stage is released
-                stamp(k, 5);
-            }
-            if constexpr (BN != 384) mma(a1, b1, std::integral_constant<int, 0>{});  // k-slice 3 of the tile's last step
-#endif
         };
         // ---- Half-tile ring K loop (RING; the counted-vmcnt 8-phase structure of the gfx950 GEMM template, on 32x32x16 MFMAs).
         //   LDS: 8 half-tile slots = 2 K-tiles x {B0, A0, B1, A1}.  An iteration is 8 phases = 2 K-tiles; phase p:
@@ -695,7 +607,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         auto kloop_ring = [&](auto swp) {
             if constexpr (RING) {
             constexpr bool SW = decltype(swp)::value;
-            constexpr bool NOXT = EPI == EPI_UP_DWCONV || EPI == EPI_UP_DWCONV2;
+            constexpr bool NOXT = EPI == EPI_UP_DWCONV2;
             using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
             const int grp = wid >> 2;
@@ -857,150 +769,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         } else {
             __builtin_amdgcn_s_barrier();          // all waves finished reading the last stage: reuse it as scratch
             char* ws = RING ? smem + 4 * HT + wid * G::SCRATCH : smem + ((g - 1) & 1) * G::STAGE_BYTES + wid * G::SCRATCH;   // (ring: slots 4-7 are free by now)
-            if constexpr (EPI == EPI_UP_DWCONV) {
-                // The tile's 256 rows are the 16x16 tokens of ONE sample, so the depthwise 3x3 conv of the MLP is
-                // tile-local: hidden = bf16(acc + bias) goes to LDS as [256 tokens][256 channels] (128 KB: both
-                // stages -- this epilogue therefore gives up the cross-tile prefetch), then every thread slides a
-                // 3x3 fp32 window along an image row for one channel quad, applies bias + exact GELU and stores 8 B.
-                // The pre-conv hidden tensor never travels to HBM (a 200 MB write + read per layer) and the separate
-                // kernel disappears.  Token rows have a 520-byte pitch (512 + 8): the 32 tokens a wave writes at one channel
-                // offset then fall on all 64 banks, and reads are plain base + column * 520 (an XOR swizzle cost ~20 VALU
-                // of address arithmetic per window step).  The image (130 KB) spills a little past the two stages.
-                static_assert(BN == 256, "fused depthwise epilogue is written for 256-column tiles");
-                char* H = smem;
-                // LayerNorm-3 folded in (p.row_stats): acc is x W'^T for the RAW residual rows; the image gets
-                // rstd_m (acc - mean_m c1[n]) + b1[n] = rs * acc + (nm * c1 + b1), lane = token row m
-                float ln_rs[G::TM], ln_nm[G::TM];
-                const bool ln3 = p.row_stats != nullptr;
-#pragma unroll
-                for (int i = 0; i < G::TM; ++i) {
-                    ln_rs[i] = 1.0f; ln_nm[i] = 0.f;
-                    if (ln3) {
-                        const float2 st = *reinterpret_cast<const float2*>(smem + G::ROWSTAT_OFF + (wm * G::WROWS + i * 32 + l31) * 8);
-                        ln_rs[i] = st.y; ln_nm[i] = -st.y * st.x;
-                    }
-                }
-                // (column-major over the wave tile: the per-column constants are fetched once per 4 columns, not once per
-                // 32-row MFMA tile -- 16 instead of 64 global loads per lane and tile)
-                if (!TLD_EPI_BIT(8))
-#pragma unroll
-                for (int j = 0; j < G::TN; ++j)
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const int cl = wn * 64 + j * 32 + 8 * rq + 4 * hi;               // channel inside the tile
-                        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + cl);
-                        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (ln3) c4 = *reinterpret_cast<const float4*>(p.ln_c1 + n0 + cl);
-#pragma unroll
-                        for (int i = 0; i < G::TM; ++i) {
-                            bf16x4 pk;
-                            pk[0] = (bf16)fmaf(ln_rs[i], acc[i][j][rq * 4 + 0], fmaf(ln_nm[i], c4.x, b4.x));
-                            pk[1] = (bf16)fmaf(ln_rs[i], acc[i][j][rq * 4 + 1], fmaf(ln_nm[i], c4.y, b4.y));
-                            pk[2] = (bf16)fmaf(ln_rs[i], acc[i][j][rq * 4 + 2], fmaf(ln_nm[i], c4.z, b4.z));
-                            pk[3] = (bf16)fmaf(ln_rs[i], acc[i][j][rq * 4 + 3], fmaf(ln_nm[i], c4.w, b4.w));
-                            const int tok = wm * G::WROWS + i * 32 + l31;
-                            *reinterpret_cast<bf16x4*>(H + tok * G::IMG_PITCH + cl * 2) = pk;
-                        }
-                    }
-                __builtin_amdgcn_s_barrier();
-                if (!TLD_EPI_BIT(4)) {
-                    const int cq = threadIdx.x & 63;                     // channel quad (64 per token row)
-                    const int c0 = n0 + cq * 4;
-                    // packed-fp32 arithmetic throughout: channel pairs {c0,c0+1} and {c0+2,c0+3} ride in f32x2 registers
-                    f32x2 w[9][2], bs[2];
-#pragma unroll
-                    for (int k9 = 0; k9 < 9; ++k9) {
-                        const float4 t = *reinterpret_cast<const float4*>(p.dw_w9c + (size_t)k9 * p.N + c0);
-                        w[k9][0] = f32x2{t.x, t.y}; w[k9][1] = f32x2{t.z, t.w};
-                    }
-                    {
-                        const float4 t = *reinterpret_cast<const float4*>(p.dw_b + c0);
-                        bs[0] = f32x2{t.x, t.y}; bs[1] = f32x2{t.z, t.w};
-                    }
-                    // each thread walks TWO image rows (irow, irow + 8) in lockstep: two independent window/FMA/GELU
-                    // chains per thread -- with 2 waves per SIMD the single-row form was latency-bound
-                    const int irow0 = threadIdx.x >> 6;                  // image rows irow0 and irow0 + 8
-                    // Image-border handling without branches: rows outside the image are read from a clamped (valid) row
-                    // and meet ZERO weights -- only the upper taps of image row 0 (wave 0) and the lower taps of image
-                    // row 15 (wave 7) are affected, so two masked copies of three taps are all it takes.  (Predicated
-                    // loads broke the window loop into ~20 exec-masked blocks per step.)
-                    f32x2 wU[3][2], wD[3][2];
-                    {
-                        const float mu = irow0 > 0 ? 1.0f : 0.0f, md = irow0 < 7 ? 1.0f : 0.0f;
-#pragma unroll
-                        for (int t3 = 0; t3 < 3; ++t3)
-#pragma unroll
-                            for (int h2 = 0; h2 < 2; ++h2) { wU[t3][h2] = w[t3][h2] * mu; wD[t3][h2] = w[6 + t3][h2] * md; }
-                    }
-                    auto col_zero = [&](f32x2 (&c)[2][3][2]) {           // image columns -1 and 16
-#pragma unroll
-                        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                            for (int du = 0; du < 3; ++du) { c[rr][du][0] = f32x2{0.f, 0.f}; c[rr][du][1] = f32x2{0.f, 0.f}; }
-                    };
-                    auto col = [&](int jj, f32x2 (&c)[2][3][2]) {        // 0 <= jj < 16
-#pragma unroll
-                        for (int rr = 0; rr < 2; ++rr) {
-                            const int irow = irow0 + rr * 8;
-#pragma unroll
-                            for (int du = 0; du < 3; ++du) {
-                                int ir = irow + du - 1;
-                                ir = ir < 0 ? 0 : (ir > 15 ? 15 : ir);
-                                const int tok = ir * 16 + jj;
-                                const bf16x4 v = *reinterpret_cast<const bf16x4*>(H + tok * G::IMG_PITCH + cq * 8);
-                                c[rr][du][0] = f32x2{(float)v[0], (float)v[1]};
-                                c[rr][du][1] = f32x2{(float)v[2], (float)v[3]};
-                            }
-                        }
-                    };
-                    bf16* dst0 = p.out_bf16 + ((size_t)m0 + irow0 * 16) * p.ldo + c0;
-                    auto emit = [&](const f32x2 (&L)[2][3][2], const f32x2 (&Mc)[2][3][2], const f32x2 (&R)[2][3][2], int jj) {
-                        f32x2 a[2][2];
-#pragma unroll
-                        for (int rr = 0; rr < 2; ++rr) { a[rr][0] = bs[0]; a[rr][1] = bs[1]; }
-                        // one FMA chain per (row, channel pair), seeded with the conv bias
-#pragma unroll
-                        for (int du = 0; du < 3; ++du)
-#pragma unroll
-                            for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                                for (int h2 = 0; h2 < 2; ++h2) {
-                                    const bool up = (rr == 0 && du == 0), dn = (rr == 1 && du == 2);      // compile-time
-                                    const f32x2 w0 = up ? wU[0][h2] : (dn ? wD[0][h2] : w[du * 3 + 0][h2]);
-                                    const f32x2 w1 = up ? wU[1][h2] : (dn ? wD[1][h2] : w[du * 3 + 1][h2]);
-                                    const f32x2 w2 = up ? wU[2][h2] : (dn ? wD[2][h2] : w[du * 3 + 2][h2]);
-                                    a[rr][h2] = __builtin_elementwise_fma(w0, L[rr][du][h2], a[rr][h2]);
-                                    a[rr][h2] = __builtin_elementwise_fma(w1, Mc[rr][du][h2], a[rr][h2]);
-                                    a[rr][h2] = __builtin_elementwise_fma(w2, R[rr][du][h2], a[rr][h2]);
-                                }
-                        if (!TLD_EPI_BIT(2)) {
-#pragma unroll
-                            for (int rr = 0; rr < 2; ++rr) { a[rr][0] = gelu_erf_fast2_half(a[rr][0]); a[rr][1] = gelu_erf_fast2_half(a[rr][1]); }
-                        }
-#pragma unroll
-                        for (int rr = 0; rr < 2; ++rr) {
-                            bf16x4 o;
-                            o[0] = (bf16)a[rr][0][0]; o[1] = (bf16)a[rr][0][1]; o[2] = (bf16)a[rr][1][0]; o[3] = (bf16)a[rr][1][1];
-                            // (no row guard: this epilogue requires M % 256 == 0 -- one whole image per tile)
-                            if (!TLD_EPI_BIT(1)) TLD_STORE(reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 128 + jj) * p.ldo), o);
-                        }
-                    };
-                    f32x2 c0v[2][3][2], c1v[2][3][2], c2v[2][3][2];
-                    col_zero(c0v);
-                    col(0, c1v);
-                    int jj = 0;
-                    for (; jj + 3 <= 16; jj += 3) {
-                        col(jj + 1, c2v); emit(c0v, c1v, c2v, jj);
-                        col(jj + 2, c0v); emit(c1v, c2v, c0v, jj + 1);
-                        col(jj + 3, c1v); emit(c2v, c0v, c1v, jj + 2);
-                    }
-                    col_zero(c2v); emit(c0v, c1v, c2v, jj);          // jj == 15
-                }
-                // the ring restarts for the next tile: its first K-step could not be prefetched (LDS was the image)
-                __builtin_amdgcn_s_barrier();
-                if constexpr (!RING) { if (has_next) issue(m0n, n0n, g); }   // (ring: the next tile starts cold in kloop_ring)
-            } else if constexpr (EPI == EPI_UP_DWCONV2) {
-                // Second form of the fused depthwise 3x3 + GELU epilogue.  The K loop runs in the NATURAL MFMA order, so a
+            if constexpr (EPI == EPI_UP_DWCONV2) {
+                // Fused depthwise 3x3 + GELU epilogue (tld/transformer_blocks.py:96-103).  The tile's 256 rows are the 16 x 16 tokens of ONE
+                // sample, so the conv of the MLP is tile-local: the pre-conv hidden tensor never travels to HBM (a 200 MB write + read per
+                // layer) and the separate kernel disappears.  (A first form -- token-major fp32 window, packed FMAs -- was retired in round 4:
+                // within 1 % of this one)  The K loop runs in the NATURAL MFMA order, so a
                 // lane owns a channel and four consecutive tokens (= four consecutive image columns of one image row)
                 // per register quad: two v_cvt_pk_bf16_f32 give the dwords (col 2q, col 2q+1) of that channel, and the
                 // image in LDS is [token pair][channel] dwords.  The conv then needs no unpacking at all: every tap
@@ -1209,6 +982,128 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         gn_combine(red);
                     }
                 }
+            } else if constexpr (EPI == EPI_QKV_ATTN) {
+                // ---- fused self-attention of (sample m0 / 256, head n0 / 192).  The accumulators hold x W'^T for the head's q | k | v columns
+                // (swapped order: lane = token row, registers = 4 consecutive columns per quad).  LayerNorm-1 is applied in place exactly as
+                // in EPI_QKV_LN, then q, k (row images, the GEMM's 128-byte rows + XOR swizzle) and v^T go to LDS and every wave runs the
+                // head's attention for 32 query rows (tld_attn_core.h).  Only att[256 x 64] is stored.
+                int e_lane = lane, e_l31 = l31, e_hi = hi;
+                asm volatile("" : "+v"(e_lane), "+v"(e_l31), "+v"(e_hi));
+                {
+                    const int tid = wid * 64 + e_lane;
+                    const int s0 = (tid & 1) * 4;
+                    const float4* raw = reinterpret_cast<const float4*>(smem + G::LN_RAW + (tid >> 1) * 64 + s0 * 8);
+                    float su = 0.f, sq = 0.f;
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2)
+                        if (s0 + 2 * q2 < p.ln_slots) {
+                            const float4 v = raw[q2];
+                            su += v.x + v.z; sq += v.y + v.w;
+                        }
+                    su = dpp_add<0xB1>(su); sq = dpp_add<0xB1>(sq);
+                    const float inv_k = 1.0f / (float)p.K;
+                    const float mu = su * inv_k;
+                    const float var = fmaxf(fmaf(sq, inv_k, -mu * mu), 0.f);
+                    if (!(tid & 1))
+                        reinterpret_cast<float2*>(smem + G::LN_ST)[tid >> 1] = make_float2(mu, __builtin_amdgcn_rsqf(var + kLnEps));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                {
+                    float rs[G::TM], nm[G::TM];
+#pragma unroll
+                    for (int i = 0; i < G::TM; ++i) {
+                        const float2 st = reinterpret_cast<const float2*>(smem + G::LN_ST)[wm * G::WROWS + i * 32 + e_l31];
+                        rs[i] = st.y; nm[i] = -st.y * st.x;
+                    }
+#pragma unroll
+                    for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const int cl = wn * G::WCOLS + j * 32 + 8 * rq + 4 * e_hi;         // column inside the tile
+                            const float4 c4 = *reinterpret_cast<const float4*>(smem + G::LN_CB + cl * 4);
+                            const float4 b4 = *reinterpret_cast<const float4*>(smem + G::LN_CB + 1024 + cl * 4);
+#pragma unroll
+                            for (int i = 0; i < G::TM; ++i) {
+                                acc[i][j][rq * 4 + 0] = fmaf(rs[i], acc[i][j][rq * 4 + 0], fmaf(nm[i], c4.x, b4.x));
+                                acc[i][j][rq * 4 + 1] = fmaf(rs[i], acc[i][j][rq * 4 + 1], fmaf(nm[i], c4.y, b4.y));
+                                acc[i][j][rq * 4 + 2] = fmaf(rs[i], acc[i][j][rq * 4 + 2], fmaf(nm[i], c4.z, b4.z));
+                                acc[i][j][rq * 4 + 3] = fmaf(rs[i], acc[i][j][rq * 4 + 3], fmaf(nm[i], c4.w, b4.w));
+                            }
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();              // every wave is done with the LayerNorm tables: the images overlay them
+                char* Kimg = smem + G::AT_K;
+                char* Vimg = smem + G::AT_V;
+                char* Qimg = smem + G::AT_Q;
+                // tile columns: [0, 64) q, [64, 128) k, [128, 192) v.  Wave column 0 owns q and k features 0-31, wave column 1 k features
+                // 32-63 and v (wn is wave-uniform: scalar branches)
+#pragma unroll
+                for (int j = 0; j < G::TN; ++j) {
+                    const int cbase = wn * G::WCOLS + j * 32;       // 0, 32, 64 | 96, 128, 160
+#pragma unroll
+                    for (int i = 0; i < G::TM; ++i) {
+                        const int row = wm * G::WROWS + i * 32 + e_l31;
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            bf16x4 pk;
+                            pk[0] = (bf16)acc[i][j][rq * 4 + 0]; pk[1] = (bf16)acc[i][j][rq * 4 + 1];
+                            pk[2] = (bf16)acc[i][j][rq * 4 + 2]; pk[3] = (bf16)acc[i][j][rq * 4 + 3];
+                            if (cbase < 128) {
+                                const int f = (cbase & 63) + 8 * rq + 4 * e_hi;        // feature inside q or k
+                                char* img = cbase < 64 ? Qimg : Kimg;
+                                *reinterpret_cast<bf16x4*>(img + row * 128 + ((((f >> 3) ^ ((row >> 1) & 7)) << 4) | ((f & 7) << 1))) = pk;
+                            } else {
+                                const int f = cbase - 128 + 8 * rq + 4 * e_hi;
+#pragma unroll
+                                for (int e2 = 0; e2 < 4; ++e2)
+                                    *reinterpret_cast<bf16*>(Vimg + (f + e2) * kAttnVPitch + row * 2) = pk[e2];
+                            }
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                {
+                    const int q0 = wid * 32;                     // this wave's query rows
+                    bf16x8 qf[4];
+                    {
+                        const int row = q0 + e_l31;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks)
+                            qf[ks] = *reinterpret_cast<const bf16x8*>(Qimg + row * 128 + (((ks * 2 + e_hi) ^ ((row >> 1) & 7)) << 4));
+                    }
+                    f32x16 o[2];
+                    const float inv = attn256_wave(Kimg, Vimg, qf, o, e_l31, e_hi);
+                    // whole 128-byte rows through a per-wave transpose patch (16 rows x 144 B), as attn1_kernel stores them; the patch overlays the
+                    // wave's OWN query rows of the Q image (read by nobody else, and this wave's reads are long retired)
+                    char* T = Qimg + wid * 4096;
+                    bf16* dst0 = p.out_bf16 + (size_t)(m0 + q0) * p.ldo + (n0 / BN) * 64;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        if ((e_l31 >> 4) == half) {
+#pragma unroll
+                            for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                                for (int rq = 0; rq < 4; ++rq) {
+                                    bf16x4 pk;
+#pragma unroll
+                                    for (int e2 = 0; e2 < 4; ++e2) pk[e2] = (bf16)(o[ct][rq * 4 + e2] * inv);
+                                    *reinterpret_cast<bf16x4*>(T + (e_l31 & 15) * 144 + ct * 64 + rq * 16 + e_hi * 8) = pk;
+                                }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+                        for (int it2 = 0; it2 < 2; ++it2) {
+                            const int r = it2 * 8 + (e_lane >> 3), c16 = e_lane & 7;
+                            const u32x4 w = *reinterpret_cast<const u32x4*>(T + r * 144 + c16 * 16);
+                            __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(dst0 + (size_t)(half * 16 + r) * p.ldo + c16 * 8));
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+                }
+                // (the next tile's K loop opens with a barrier: every wave is out of the images before stage 1 is written again)
             } else if constexpr (G::WCOLS == 64) {
                 // lane-derived values re-materialised per tile: otherwise every address expression of this epilogue is
                 // hoisted out of the tile loop and lives (or spills) across the K loops
@@ -1383,15 +1278,12 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     // four groups for the up-projection (neutral), two / four groups for the down-projection (A is the 201 MB
     // operand there: neutral / 175 -> 195 us).  Large launches only: every XCD cell needs workgroups of its own.
     // half-tile ring K loop (256 x 256 tiles, bf16, no conv): an iteration is two K-tiles, so K must be a multiple of 128
-    static const bool ring_env = !(getenv("TLD_GEMM_RING") && atoi(getenv("TLD_GEMM_RING")) == 0);        // A/B knob
-    static const int ring_mask = getenv("TLD_GEMM_RING_MASK") ? atoi(getenv("TLD_GEMM_RING_MASK")) : 0x7f;   // A/B knob: bit e = epilogue e may use the ring
-    const bool use_ring = p.conv ? (ring_env && ((ring_mask >> epilogue) & 1) && (9 * (p.cv_cin >> 6)) % 2 == 0 && !(getenv("TLD_CONV_RING") && atoi(getenv("TLD_CONV_RING")) == 0))
-                                 : (ring_env && ((ring_mask >> epilogue) & 1) && p.K >= 128 && p.K % 128 == 0);      // (conv: K = 9 cv_cin, an even number of 64-wide K-tiles)
+    const bool use_ring = p.conv ? (9 * (p.cv_cin >> 6)) % 2 == 0 : (p.K >= 128 && p.K % 128 == 0);      // (conv: K = 9 cv_cin, an even number of 64-wide K-tiles)
     (void)use_ring;
     GemmParams pg = p;
-    static const bool half_tail = !(getenv("TLD_GEMM_HALFTAIL") && atoi(getenv("TLD_GEMM_HALFTAIL")) == 0);     // A/B knob
+    static const bool half_tail = !(getenv("TLD_GEMM_HALFTAIL") && atoi(getenv("TLD_GEMM_HALFTAIL")) == 0);     // test hook: tests/test_gpu_parity.py holds the row-split tail bitwise equal to the unsplit run
     pg.half_tail = half_tail ? 1 : 0;
-    if ((epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
+    if ((epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
         pg.xcd_ngroups = 2;
 #define TLD_L256P_(E, F8) TLD_L256P__(E, F8, false)
 #define TLD_L256P_LAUNCH(E, F8, CV, RG)                                                               \
@@ -1405,8 +1297,8 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
 #define TLD_L256P__(E, F8, CV)                                                                        \
     do {                                                                                              \
         constexpr int lds = (F8) ? G::LDS_BYTES + 4096                                                \
-                            : ((E) == EPI_UP_DWCONV && G::UPDW_LDS > G::LDS_BYTES ? G::UPDW_LDS       \
                             : ((E) == EPI_UP_DWCONV2 ? G::UPDW2_LDS                                   \
+                            : ((E) == EPI_QKV_ATTN ? G::ATTN_LDS                                      \
                             : ((E) == EPI_QKV_LN ? G::QKVLN_LDS                                        \
                             : ((E) == EPI_BIAS_BF16 && BN != 384 ? G::PLAINLN_LDS : G::LDS_BYTES))));  /* (384-wide: 160 KB of stages, no LayerNorm-3 fold) */ \
         constexpr bool ring_ok = TLD_KLOOP_RING && BN == 256 && !(F8);                                \
@@ -1441,7 +1333,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     } else if constexpr (BN == 384) {       // residual add (the down projection) and, for the training step's N = 768 linears, bias -> bf16
         if (epilogue == EPI_BIAS_BF16) TLD_L256P(EPI_BIAS_BF16); else TLD_L256P(EPI_BIAS_RESID);
     } else if constexpr (BN == 192) {
-        TLD_L256P(EPI_BIAS_RESID);
+        if (epilogue == EPI_QKV_ATTN) TLD_L256P(EPI_QKV_ATTN); else TLD_L256P(EPI_BIAS_RESID);
     } else {
         switch (epilogue) {
             case EPI_F32: TLD_L256P(EPI_F32); break;
@@ -1449,7 +1341,6 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
             case EPI_QKV_LN: TLD_L256P(EPI_QKV_LN); break;
             case EPI_BIAS_BF16: TLD_L256P(EPI_BIAS_BF16); break;
             case EPI_BIAS_RESID: TLD_L256P(EPI_BIAS_RESID); break;
-            case EPI_UP_DWCONV: if constexpr (BN == 256) { TLD_L256P(EPI_UP_DWCONV); } break;
             case EPI_UP_DWCONV2: if constexpr (BN == 256) { TLD_L256P(EPI_UP_DWCONV2); } break;
             default: break;
         }
@@ -1471,21 +1362,19 @@ int choose_bn(long M, long N, int epilogue) {
     // (a last round that is at least 85 % full counts as whole: 252 tiles on 256 CUs are not a reason to halve the tile)
     const long rounds256 = (blocks256 + 255) / 256;
     const bool narrow = (N % 256 != 0) || (blocks256 * 100 < rounds256 * 256 * 85 && blocks256 < 3 * 256);
-    static const char* force = getenv("TLD_GEMM_BN");             // experiment knob
     int bn = narrow ? 128 : 256;
     if (narrow && epilogue == EPI_BIAS_RESID && N % 192 == 0 && (ntm * (N / 192)) % 256 == 0) bn = 192;
     // down projection at the bench size: 256 x 384 tiles make N = 768 ONE round of 256 workgroups (176 -> 155 us);
     // any other batch size of that width uses 192-wide tiles, never 128 / 256: both 192 and 384 give 96-column wave
     // tiles, which is what the LayerNorm-1 partial sums are defined on (results must not depend on the batch size)
-    static const bool wide = !(getenv("TLD_DOWN_BN384") && atoi(getenv("TLD_DOWN_BN384")) == 0);     // A/B knob
     if (epilogue == EPI_BIAS_RESID && N % 192 == 0) bn = 192;
-    if (wide && epilogue == EPI_BIAS_RESID && N % 384 == 0 && (ntm * (N / 384)) % 256 == 0) bn = 384;
-    if (force) bn = atoi(force);
-    if (epilogue == EPI_UP_DWCONV || epilogue == EPI_UP_DWCONV2) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
+    if (epilogue == EPI_BIAS_RESID && N % 384 == 0 && (ntm * (N / 384)) % 256 == 0) bn = 384;
+    if (epilogue == EPI_UP_DWCONV2) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
+    if (epilogue == EPI_QKV_ATTN) return 192;       // one tile = one (sample, head): caller guarantees N = heads x 192, ntok == 256
     if (bn == 192 && (epilogue != EPI_BIAS_RESID || N % 192)) bn = 128;
     // N = 768 with the plain bias epilogue (the training step's five per layer): one round of 256 x 384 tiles at the training batch instead of
     // three rounds of 256 x 128 (0.71 -> 1.0 PFLOP/s)
-    if (wide && !force && epilogue == EPI_BIAS_BF16 && N % 384 == 0 && N < 1536 && (ntm * (N / 384)) % 256 == 0) bn = 384;      // (callers with a LayerNorm-3 fold have N = 4 d >= 1536)
+    if (epilogue == EPI_BIAS_BF16 && N % 384 == 0 && N < 1536 && (ntm * (N / 384)) % 256 == 0) bn = 384;      // (callers with a LayerNorm-3 fold have N = 4 d >= 1536)
     if (bn == 384 && ((epilogue != EPI_BIAS_RESID && epilogue != EPI_BIAS_BF16) || N % 384)) bn = 128;
     if (bn != 256 && bn != 192 && bn != 384) bn = 128;
     return bn;
@@ -1493,7 +1382,7 @@ int choose_bn(long M, long N, int epilogue) {
 }  // namespace
 
 int gemm_resid_stat_slots(int N) {
-    return (N % 192 == 0 && N / 96 <= kLnSlots && !getenv("TLD_GEMM_BN")) ? N / 96 : 0;
+    return (N % 192 == 0 && N / 96 <= kLnSlots) ? N / 96 : 0;
 }
 
 void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
         fetch(ibase + 2 * (size_t)pr + 1, xr[1], ar[1]);
     }
 
-    if (!(p.dbg & 2)) {
+    {
         const float4* wl = reinterpret_cast<const float4*>(p.wq + (size_t)tl * H * d);
         const float4* wn = reinterpret_cast<const float4*>(p.wq + (size_t)tn * H * d);
         float4* dst = reinterpret_cast<float4*>(wd);
@@ -462,95 +462,113 @@ __global__ __launch_bounds__(256, 3) void cross_row_kernel(CrossRowParams p, int
     }
 }
 
-// d % 256 == 0 form of the kernel above: lane l holds features {4l .. 4l+3} + 256 j (8-byte loads and stores of the
-// bf16 streams instead of 4-byte ones; LayerNorm measured 20 -> 18 us from that alone).  The features of group j
-// in lane l belong to head 4j + (l >> 4), so the four logit sums of a head quartet are finished with two
-// v_permlane32_swap, one v_permlane16_swap and one 16-lane DPP reduction: row q of the wave ends with head 4j+q.
-// BW (round 3): the folded query-difference table is kept in LDS as bf16 and the centred rows are packed to bf16 for the 12 logit dot
-// products, which then run on v_dot2_f32_bf16 (fp32 accumulate) -- half the LDS bytes per row (reading the fp32 table, 18 KB per row, was what
-// the logits cost: 11 of the kernel's 45 us) and half the instructions.  No MFMA runs in this kernel, so the dot instructions cost nothing
-// extra here.  Same operand precision as every GEMM of the path.  OFF by default (TLD_CROSS_BF16=1 selects it): see launch_cross_row.
-template <int NQ, bool BW>
-__global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, int chunks_per_sample) {
+// ------------------------------------------------------------------------------------------------
+// d % 256 == 0 (the 100 M model): lane l holds features {4l .. 4l+3} + 256 j -- 8-byte loads and stores of the bf16 streams -- and the
+// per-head logit dot products run on the MATRIX pipe (round 4; up to 16 heads).
+// The 4 H d fp32 MACs per row pair of the round-3 VALU kernel (cross_row_q4_kernel, lane = 4 features + 256 j; retired) were 11 of its 46 us at C1 (profiles/r03_cross_row_attribution.txt) with the
+// matrix cores idle.  Here a 512-thread workgroup walks 16-row groups of one sample: every wave brings in one row pair (the next pair's
+// loads in flight), forms x1 = x + att and its LayerNorm-2 statistics as before, and parks the CENTRED rows in an LDS tile [16][d] as a
+// SPLIT bf16 pair (hi = bf16(c), lo = bf16(c - hi): 16 significant bits; centring first keeps rows with a large common offset exact, g9).
+// After one barrier the tile's logits against the H folded query-difference vectors are v_mfma_f32_16x16x32_bf16 products
+// hi.hi + lo.hi + hi.lo (fp32 accumulate: the logits keep fp32-grade accuracy, which plain bf16 operands did not: forward rel-rms
+// 6.5e-3 instead of 6.3e-3 on g5) with the K range split over the eight waves: wave w multiplies features [d w / 8, d (w + 1) / 8), whose
+// slices of the query-difference vectors (split the same way) it keeps in REGISTERS for the whole launch -- no table in LDS, no table fill.
+// D[head][row] partials land with a lane = (row, head quad) and cross the waves through 8 KB of LDS (second barrier); every wave then sums
+// the eight partials of its own two rows, applies rstd and the beta term, takes the sigmoids and finishes its rows as before.
+// LDS images: 16-byte chunk c of row r at chunk c ^ r: conflict-free for the row writes (ds_write_b64) and for the MFMA operand reads (a
+// ds_read_b128 lane group mixes two k-quarters of eight rows each; chunk = 4 kb + kq keeps their slots apart).
+template <int NQ>
+__global__ __launch_bounds__(512) void cross_row_mfma_kernel(CrossRowParams p, int groups_per_wg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int d = NQ * 256, H = NQ * 4;
+    constexpr int d = NQ * 256, H = NQ * 4, PITCH = d * 2;
     constexpr float inv_d = 1.0f / (float)d;
-    float* wd = reinterpret_cast<float*>(smem);          // [H][d]  wq_label - wq_noise (gamma folded); BW: bf16 [H][d] in the first half
-    float* vn = wd + (BW ? H * d / 2 : H * d);           // [d]     value row of the noise token
-    float* vdiff = vn + d;                               // [d]     v_label - v_noise
-    float* bw = vdiff + d;                               // [H]     beta contribution to the logit diff
+    char* tileH = smem;                                              // [16][PITCH] bf16 hi halves of the group's centred rows
+    char* tileL = tileH + 16 * PITCH;                                // [16][PITCH] lo halves
+    float* part = reinterpret_cast<float*>(tileL + 16 * PITCH);      // [8 waves][16 rows][16 heads] partial logits
+    float* vn = part + 8 * 256;                                      // [d] value row of the noise token
+    float* vdiff = vn + d;                                           // [d] v_label - v_noise
 
-    const int b = blockIdx.x / chunks_per_sample;
-    const int ck = blockIdx.x - b * chunks_per_sample;
-    const int pairs = p.ntok >> 1;
-    const int pp0 = (int)((long)ck * pairs / chunks_per_sample);
-    const int pp1 = (int)((long)(ck + 1) * pairs / chunks_per_sample);
+    const int wgs_per_sample = (p.ntok >> 4) / groups_per_wg;
+    const int b = blockIdx.x / wgs_per_sample;
+    const int g0 = (blockIdx.x - b * wgs_per_sample) * groups_per_wg;   // first 16-row group of this workgroup inside the sample
     const int tn = p.noise_row[b], tl = p.label_row[b];
-
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const resid_t* xin = p.x_in ? p.x_in : p.x;
     const size_t obase = (size_t)b * p.ntok;
     const size_t ibase = p.x_in ? (size_t)(b % p.src_batch) * p.ntok : obase;
 
-    float4 xr[2][NQ];
-    bf16x4 ar[2][NQ];
-    auto fetch = [&](size_t row, float4 (&xv)[NQ], bf16x4 (&av)[NQ]) {
+    auto pair_row = [&](int g) { return 16 * (g0 + g) + 2 * wid; };   // this wave's row pair of group g (row inside the sample)
+    // two row pairs in flight per wave behind the one being processed (16 waves x 12 KB = 96 KB per CU: with one pair the kernel sat at
+    // Little's-law parity with the HBM latency): buffers A and B alternate between even and odd groups
+    resid4_t xrA[2][NQ], xrB[2][NQ];
+    bf16x4 arA[2][NQ], arB[2][NQ];
+    auto fetch = [&](size_t row, resid4_t (&xv)[NQ], bf16x4 (&av)[NQ]) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             const int n = j * 256 + 4 * lane;
-            xv[j] = rs_load4(xin + row * d + n);
+            xv[j] = rs_raw4(xin + row * d + n);
             av[j] = *reinterpret_cast<const bf16x4*>(p.att + row * d + n);
         }
     };
-    int pr = pp0 + wid;
-    if (pr < pp1) {
-        fetch(ibase + 2 * (size_t)pr, xr[0], ar[0]);
-        fetch(ibase + 2 * (size_t)pr + 1, xr[1], ar[1]);
+    fetch(ibase + pair_row(0), xrA[0], arA[0]);
+    fetch(ibase + pair_row(0) + 1, xrA[1], arA[1]);
+    if (groups_per_wg > 1) {
+        fetch(ibase + pair_row(1), xrB[0], arB[0]);
+        fetch(ibase + pair_row(1) + 1, xrB[1], arB[1]);
     }
+
+    const int tok = lane & 15, kq = lane >> 4;                       // MFMA roles: row of an operand / output column, and k-quarter / head quad
+    // A operand (rows = heads), this wave's K slice, split hi / lo: K-block kb = wid NQ + s2 covers features 32 kb .. 32 kb + 31, of which this
+    // lane holds 8 kq .. 8 kq + 7.  (Operand rows H .. 15 repeat the last head: their outputs are never read.)
+    bf16x8 wh[NQ], wlo[NQ];
     {
-        const float4* wl = reinterpret_cast<const float4*>(p.wq + (size_t)tl * H * d);
-        const float4* wn = reinterpret_cast<const float4*>(p.wq + (size_t)tn * H * d);
-        float4* dst = reinterpret_cast<float4*>(wd);
-        for (int i = threadIdx.x; i < H * d / 4; i += 256) {
-            const float4 a = wl[i], c = wn[i];
-            if constexpr (BW) {
-                bf16x4 o;
-                o[0] = (bf16)(a.x - c.x); o[1] = (bf16)(a.y - c.y); o[2] = (bf16)(a.z - c.z); o[3] = (bf16)(a.w - c.w);
-                reinterpret_cast<bf16x4*>(wd)[i] = o;
-            } else {
-                dst[i] = make_float4(a.x - c.x, a.y - c.y, a.z - c.z, a.w - c.w);
+        const int hrow = tok < H ? tok : H - 1;
+        const float* wlp = p.wq + ((size_t)tl * H + hrow) * d;
+        const float* wnp = p.wq + ((size_t)tn * H + hrow) * d;
+#pragma unroll
+        for (int s2 = 0; s2 < NQ; ++s2) {
+            const int f = 32 * (wid * NQ + s2) + 8 * kq;
+            const float4 a0 = *reinterpret_cast<const float4*>(wlp + f), a1 = *reinterpret_cast<const float4*>(wlp + f + 4);
+            const float4 c0 = *reinterpret_cast<const float4*>(wnp + f), c1 = *reinterpret_cast<const float4*>(wnp + f + 4);
+            const float df[8] = {a0.x - c0.x, a0.y - c0.y, a0.z - c0.z, a0.w - c0.w, a1.x - c1.x, a1.y - c1.y, a1.z - c1.z, a1.w - c1.w};
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) {
+                const bf16 hi = (bf16)df[e2];
+                wh[s2][e2] = hi;
+                wlo[s2][e2] = (bf16)(df[e2] - (float)hi);
             }
         }
     }
-    for (int i = threadIdx.x; i < d; i += 256) {
+    for (int i = threadIdx.x; i < d; i += 512) {
         const float a = p.v[(size_t)tn * p.v_ld + i];
         vn[i] = a;
         vdiff[i] = p.v[(size_t)tl * p.v_ld + i] - a;
     }
-    if (threadIdx.x < H) bw[threadIdx.x] = p.bwq[(size_t)tl * H + threadIdx.x] - p.bwq[(size_t)tn * H + threadIdx.x];
-    __syncthreads();
-    const bool fold3 = p.ln3_stats != nullptr;
+    // lane's features of group j belong to head 4 j + (lane >> 4): beta contribution to that head's logit difference
     float bwl[NQ];
 #pragma unroll
-    for (int hg = 0; hg < NQ; ++hg) bwl[hg] = bw[4 * hg + (lane >> 4)];
+    for (int j = 0; j < NQ; ++j) bwl[j] = p.bwq[(size_t)tl * H + 4 * j + (lane >> 4)] - p.bwq[(size_t)tn * H + 4 * j + (lane >> 4)];
+    const bool fold3 = p.ln3_stats != nullptr;
 
-    for (; pr < pp1; pr += 4) {
-        f32x4 v[2][NQ];
+    auto step = [&](int g, resid4_t (&xr)[2][NQ], bf16x4 (&ar)[2][NQ]) {
+        // ---- phase A: the wave's row pair -> x1, LayerNorm-2 statistics, centred split-bf16 rows into the tile
+        f32x4 v[2][NQ];                                              // x1 = x + att, fp32
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                v[u][j][0] = xr[u][j].x + (float)ar[u][j][0];        // x = SA(LN1 x) + x
-                v[u][j][1] = xr[u][j].y + (float)ar[u][j][1];
-                v[u][j][2] = xr[u][j].z + (float)ar[u][j][2];
-                v[u][j][3] = xr[u][j].w + (float)ar[u][j][3];
+                const float4 xw = rs_widen4(xr[u][j]);
+                v[u][j][0] = xw.x + (float)ar[u][j][0];              // x = SA(LN1 x) + x
+                v[u][j][1] = xw.y + (float)ar[u][j][1];
+                v[u][j][2] = xw.z + (float)ar[u][j][2];
+                v[u][j][3] = xw.w + (float)ar[u][j][3];
             }
-        const size_t row = obase + 2 * (size_t)pr;
-        if (pr + 4 < pp1) {
-            fetch(ibase + 2 * (size_t)(pr + 4), xr[0], ar[0]);
-            fetch(ibase + 2 * (size_t)(pr + 4) + 1, xr[1], ar[1]);
+        if (g + 2 < groups_per_wg) {
+            fetch(ibase + pair_row(g + 2), xr[0], ar[0]);
+            fetch(ibase + pair_row(g + 2) + 1, xr[1], ar[1]);
         }
+        const size_t row = obase + pair_row(g);
         if (p.sa_out) {
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -558,86 +576,58 @@ __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, 
                 for (int j = 0; j < NQ; ++j)
                     *reinterpret_cast<f32x4*>(p.sa_out + (row + u) * d + j * 256 + 4 * lane) = v[u][j];
         }
-        float mean[2], rstd[2];
+        float rstd[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             f32x4 s4 = v[u][0];
 #pragma unroll
             for (int j = 1; j < NQ; ++j) s4 += v[u][j];
-            mean[u] = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_d;
-        }
-        f32x4 c[2][NQ];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
+            const float mean = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_d;
             f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+            const int gr = 2 * wid + u;                              // row inside the group's tile
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                c[u][j] = v[u][j] - mean[u];
-                q4 = __builtin_elementwise_fma(c[u][j], c[u][j], q4);
+                const f32x4 c = v[u][j] - mean;
+                q4 = __builtin_elementwise_fma(c, c, q4);
+                bf16x4 oh, ol;
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) { oh[e2] = (bf16)c[e2]; ol[e2] = (bf16)(c[e2] - (float)oh[e2]); }
+                const int off = gr * PITCH + ((((32 * j + (lane >> 1)) ^ gr) << 4) | ((lane & 1) << 3));
+                *reinterpret_cast<bf16x4*>(tileH + off) = oh;
+                *reinterpret_cast<bf16x4*>(tileL + off) = ol;
             }
             rstd[u] = __builtin_amdgcn_rsqf(fmaf(wave_sum((q4[0] + q4[1]) + (q4[2] + q4[3])), inv_d, kLnEps));
         }
-
-        float plab[2][NQ];
-        if (p.dbg & 1) {
+        __syncthreads();                                             // the group's 16 rows are in LDS (and nobody still reads last group's partials)
+        // ---- phase B: this wave's K slice of the tile's logits on the matrix pipe, D[head 4 kq + r][row tok] partial
+        {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int hg = 0; hg < NQ; ++hg) { plab[0][hg] = 0.5f * rstd[0]; plab[1][hg] = 0.5f * rstd[1]; }
-        } else
-#pragma unroll
-        for (int hg = 0; hg < NQ; ++hg) {
-            float part[2][4];
-            if constexpr (BW) {
-                union pk4 { bf16x4 v; bf16x2 h[2]; };
-                pk4 cp[2][NQ];                        // (re-packed per head quartet: keeping them live across the loop costs registers)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j) { cp[u][j].v[0] = (bf16)c[u][j][0]; cp[u][j].v[1] = (bf16)c[u][j][1]; cp[u][j].v[2] = (bf16)c[u][j][2]; cp[u][j].v[3] = (bf16)c[u][j][3]; }
-#pragma unroll
-                for (int hh = 0; hh < 4; ++hh) {
-                    float acc[2] = {0.f, 0.f};
-                    const bf16* w0 = reinterpret_cast<const bf16*>(wd) + (4 * hg + hh) * d + 4 * lane;
-#pragma unroll
-                    for (int j = 0; j < NQ; ++j) {
-                        pk4 a;
-                        a.v = *reinterpret_cast<const bf16x4*>(w0 + j * 256);
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            acc[u] = __builtin_amdgcn_fdot2_f32_bf16(cp[u][j].h[0], a.h[0], acc[u], false);
-                            acc[u] = __builtin_amdgcn_fdot2_f32_bf16(cp[u][j].h[1], a.h[1], acc[u], false);
-                        }
-                    }
-                    part[0][hh] = acc[0]; part[1][hh] = acc[1];
-                }
-            } else
-#pragma unroll
-            for (int hh = 0; hh < 4; ++hh) {
-                f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-                const float* w0 = wd + (4 * hg + hh) * d + 4 * lane;
-#pragma unroll
-                for (int j = 0; j < NQ; ++j) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(w0 + j * 256);
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[u] = __builtin_elementwise_fma(c[u][j], a, acc[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) part[u][hh] = (acc[u][0] + acc[u][1]) + (acc[u][2] + acc[u][3]);
+            for (int s2 = 0; s2 < NQ; ++s2) {
+                const int off = tok * PITCH + (((4 * (wid * NQ + s2) + kq) ^ tok) << 4);
+                const bf16x8 ch = *reinterpret_cast<const bf16x8*>(tileH + off);
+                const bf16x8 cl = *reinterpret_cast<const bf16x8*>(tileL + off);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s2], ch, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s2], cl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo[s2], ch, acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const auto s02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[u][0]), __float_as_uint(part[u][2]), false, false);
-                const auto s13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[u][1]), __float_as_uint(part[u][3]), false, false);
-                const float a02 = __uint_as_float(s02[0]) + __uint_as_float(s02[1]);      // lanes 0-31: head 0, 32-63: head 2
-                const float a13 = __uint_as_float(s13[0]) + __uint_as_float(s13[1]);      // lanes 0-31: head 1, 32-63: head 3
-                const auto sr = __builtin_amdgcn_permlane16_swap(__float_as_uint(a02), __float_as_uint(a13), false, false);
-                float t = __uint_as_float(sr[0]) + __uint_as_float(sr[1]);                // wave row q: head q
-                t = dpp_add<0xB1>(t); t = dpp_add<0x4E>(t); t = dpp_add<0x141>(t); t = dpp_add<0x140>(t);
-                const float dl = t * rstd[u] + bwl[hg];
-                plab[u][hg] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-dl * 1.44269504088896340736f));
-            }
-            __builtin_amdgcn_sched_barrier(0);     // keep the next head quartet's LDS reads from being hoisted (VGPRs)
+            *reinterpret_cast<f32x4*>(part + (wid * 16 + tok) * 16 + 4 * kq) = acc;
         }
-        // x += p_noise v_n + p_label v_l ; then LN3
+        __syncthreads();                                             // all eight K slices are in; the tile is free for the next group's rows
+        // ---- phase C: logits of the wave's own two rows -> sigmoid weights; blend the two value rows, store, LayerNorm-3
+        float plab[2][NQ];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const float* pp = part + (2 * wid + u) * 16 + 4 * j + (lane >> 4);
+                float t = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < 8; ++w2) t += pp[w2 * 256];
+                const float dl = fmaf(t, rstd[u], bwl[j]);
+                plab[u][j] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-dl * 1.44269504088896340736f));
+                __builtin_amdgcn_sched_barrier(0);          // (one (row, head) at a time: 48 partials in flight at once cost 40 registers)
+            }
         float mean3[2], rstd3[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -673,28 +663,32 @@ __global__ __launch_bounds__(256, 3) void cross_row_q4_kernel(CrossRowParams p, 
                 p.ln3_stats[row] = make_float2(mean3[0], rstd3[0]);
                 p.ln3_stats[row + 1] = make_float2(mean3[1], rstd3[1]);
             }
-            continue;
-        }
+        } else {
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const int n = j * 256 + 4 * lane;
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(p.ln3_w + n);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln3_b + n);
+            for (int j = 0; j < NQ; ++j) {
+                const int n = j * 256 + 4 * lane;
+                const f32x4 gg = *reinterpret_cast<const f32x4*>(p.ln3_w + n);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(p.ln3_b + n);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const f32x4 r = __builtin_elementwise_fma(v[u][j] * rstd3[u], gg, bb);
-                bf16x4 o;
-                o[0] = (bf16)r[0]; o[1] = (bf16)r[1]; o[2] = (bf16)r[2]; o[3] = (bf16)r[3];
-                if (p.xn3_f8) {      // fp8 GEMM mode: MX-quantise the bf16-rounded row in place of the bf16 store
-                    int e8;
-                    const unsigned w = mx8_pack4((float)o[0], (float)o[1], (float)o[2], (float)o[3], &e8);
-                    *reinterpret_cast<unsigned*>(p.xn3_f8 + (row + u) * d + n) = w;
-                    if ((lane & 7) == 0) p.xn3_s8[mx8_scale_index(n, row + u, (size_t)p.batch * p.ntok)] = (uint8_t)e8;
-                } else {
-                    *reinterpret_cast<bf16x4*>(p.xn3 + (row + u) * d + n) = o;
+                for (int u = 0; u < 2; ++u) {
+                    const f32x4 r = __builtin_elementwise_fma(v[u][j] * rstd3[u], gg, bb);
+                    bf16x4 o;
+                    o[0] = (bf16)r[0]; o[1] = (bf16)r[1]; o[2] = (bf16)r[2]; o[3] = (bf16)r[3];
+                    if (p.xn3_f8) {      // fp8 GEMM mode: MX-quantise the bf16-rounded row in place of the bf16 store
+                        int e8;
+                        const unsigned w = mx8_pack4((float)o[0], (float)o[1], (float)o[2], (float)o[3], &e8);
+                        *reinterpret_cast<unsigned*>(p.xn3_f8 + (row + u) * d + n) = w;
+                        if ((lane & 7) == 0) p.xn3_s8[mx8_scale_index(n, row + u, (size_t)p.batch * p.ntok)] = (uint8_t)e8;
+                    } else {
+                        *reinterpret_cast<bf16x4*>(p.xn3 + (row + u) * d + n) = o;
+                    }
                 }
             }
         }
+    };
+    for (int g = 0; g < groups_per_wg; g += 2) {
+        step(g, xrA, arA);
+        if (g + 1 < groups_per_wg) step(g + 1, xrB, arB);
     }
 }
 
@@ -1030,11 +1024,10 @@ void launch_embed(const EmbedParams& p, hipStream_t s) {
 
 void launch_layernorm_bf16(const resid_t* x, const float* g, const float* b, bf16* out, int M, int d,
                            hipStream_t s) {
-    static const bool q4 = !(getenv("TLD_LN_Q4") && atoi(getenv("TLD_LN_Q4")) == 0);      // A/B knob
-    if (q4 && d == 768) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
-    if (q4 && d == 512) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
-    if (q4 && d == 256) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
-    if (q4 && d == 1024) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
+    if (d == 768) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
+    if (d == 512) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
+    if (d == 256) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
+    if (d == 1024) { hipLaunchKernelGGL(layernorm_bf16_q4_kernel<4>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d); return; }
     TLD_DISPATCH_D(d, hipLaunchKernelGGL((layernorm_bf16_kernel<NJ, HALF>), dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, out, M, d));
 }
 
@@ -1049,19 +1042,29 @@ void launch_layernorm_mx8(const resid_t* x, const float* g, const float* b, uint
     else if (d == 1024) hipLaunchKernelGGL(layernorm_mx8_kernel<4>, gr, bl, 0, s, x, g, b, out8, scale8, M, d);
 }
 
-// the LN3-statistics output (CrossRowParams::ln3_stats) exists in the 4-features-per-lane kernel only
-bool cross_row_supports_ln3_stats(int d) {
-    static const bool q4 = !(getenv("TLD_CROSS_Q4") && atoi(getenv("TLD_CROSS_Q4")) == 0);
-    return q4 && (d == 768 || d == 512 || d == 256);
-}
+// the LN3-statistics output (CrossRowParams::ln3_stats) exists in the matrix-pipe kernel only
+bool cross_row_supports_ln3_stats(int d) { return d == 768 || d == 512 || d == 256; }
 
-void launch_cross_row(const CrossRowParams& p_in, hipStream_t s) {
-    static const int dbg_env = getenv("TLD_CROSS_DBG") ? atoi(getenv("TLD_CROSS_DBG")) : 0;
-    CrossRowParams pd = p_in; pd.dbg = dbg_env;
-    const CrossRowParams& p = pd;
-    // ~43 KB of LDS per workgroup -> 3 workgroups per CU.  Split each sample's row pairs into the number of
-    // chunks that makes the grid ONE full resident round (768 workgroups on 256 CUs) when the batch allows,
-    // else k rounds of <= ~48 rows per workgroup; a partial extra round costs as much as a full one.
+void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
+    if (p.d % 256 == 0 && p.d <= 1024 && p.ntok % 16 == 0) {
+        // 512-thread workgroups over 16-row groups of one sample, ONE per CU (the kernel holds ~190 registers at d = 768: the split-bf16 slices of
+        // the query-difference vectors and two prefetched row pairs live in registers; two workgroups per CU at 128 registers spilled and ran
+        // 43.7 us against 38.0).  Groups per workgroup: the largest power of two (<= 16) that divides a sample's groups and still leaves >= 1
+        // workgroup per CU (at C1: 128 samples x 16 groups / 8 = 256 workgroups = one resident round)
+        const int gps = p.ntok / 16;
+        const long want = device_cu_count();
+        int gpw = 1;
+        while (gpw < 16 && gps % (gpw * 2) == 0 && (long)p.batch * (gps / (gpw * 2)) >= want) gpw *= 2;
+        const int ldsm = 2 * 16 * p.d * 2 + 8 * 256 * 4 + 2 * p.d * 4;     // split-bf16 tile, partial logits, the two value rows
+        dim3 gridm((unsigned)(p.batch * (gps / gpw)));
+#define TLD_CRM(NQ) do { TLD_LDS_OPT_IN((cross_row_mfma_kernel<NQ>), ldsm); hipLaunchKernelGGL((cross_row_mfma_kernel<NQ>), gridm, dim3(512), ldsm, s, p, gpw); } while (0)
+        if (p.d == 256) TLD_CRM(1); else if (p.d == 512) TLD_CRM(2); else if (p.d == 768) TLD_CRM(3); else TLD_CRM(4);
+#undef TLD_CRM
+        return;
+    }
+    // other widths (any multiple of 64): the 2-features-per-lane VALU kernel.  ~43 KB of LDS per workgroup -> 3 workgroups per CU.  Split each
+    // sample's row pairs into the number of chunks that makes the grid ONE full resident round (768 workgroups on 256 CUs) when the batch
+    // allows, else k rounds of <= ~48 rows per workgroup; a partial extra round costs as much as a full one.
     const int slots = 3 * device_cu_count();
     const long rows = (long)p.batch * p.ntok;
     const long k = (rows + (long)slots * 48 - 1) / ((long)slots * 48);
@@ -1071,20 +1074,6 @@ void launch_cross_row(const CrossRowParams& p_in, hipStream_t s) {
     if (cps < 1) cps = 1;
     const int lds = (p.heads * p.d + 2 * p.d + p.heads) * (int)sizeof(float);
     dim3 grid((unsigned)(p.batch * cps));
-    static const bool q4 = !(getenv("TLD_CROSS_Q4") && atoi(getenv("TLD_CROSS_Q4")) == 0);      // A/B knob
-    // bf16 logit table + v_dot2: measured 46.8 -> 44.4 us per launch (+0.5 % end to end) for a forward rel-rms of 6.5e-3 instead of 6.3e-3 (g5):
-    // not worth the precision; opt-in (profiles/r03_cross_row_bf16_logits.txt)
-    static const bool bw = getenv("TLD_CROSS_BF16") && atoi(getenv("TLD_CROSS_BF16")) != 0;
-    if (q4 && bw && (p.d == 768 || p.d == 512 || p.d == 256)) {
-        const int lds16 = (p.heads * p.d / 2 + 2 * p.d + p.heads) * (int)sizeof(float);
-        if (p.d == 768) hipLaunchKernelGGL((cross_row_q4_kernel<3, true>), grid, dim3(256), lds16, s, p, (int)cps);
-        else if (p.d == 512) hipLaunchKernelGGL((cross_row_q4_kernel<2, true>), grid, dim3(256), lds16, s, p, (int)cps);
-        else hipLaunchKernelGGL((cross_row_q4_kernel<1, true>), grid, dim3(256), lds16, s, p, (int)cps);
-        return;
-    }
-    if (q4 && p.d == 768) { hipLaunchKernelGGL((cross_row_q4_kernel<3, false>), grid, dim3(256), lds, s, p, (int)cps); return; }
-    if (q4 && p.d == 512) { hipLaunchKernelGGL((cross_row_q4_kernel<2, false>), grid, dim3(256), lds, s, p, (int)cps); return; }
-    if (q4 && p.d == 256) { hipLaunchKernelGGL((cross_row_q4_kernel<1, false>), grid, dim3(256), lds, s, p, (int)cps); return; }
     TLD_DISPATCH_D(p.d, { TLD_LDS_OPT_IN((cross_row_kernel<NJ, HALF>), lds); hipLaunchKernelGGL((cross_row_kernel<NJ, HALF>), grid, dim3(256), lds, s, p, (int)cps); });
 }
 
@@ -1243,8 +1232,7 @@ __global__ __launch_bounds__(320, 4) void dwconv_gelu_stream_kernel(const bf16* 
 void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c, const float* bias, const float* w9c_half,
                         const float* bias_half, int batch, int grid, int channels, hipStream_t s, uint8_t* out8,
                         uint8_t* scale8) {
-    static const bool stream_on = !(getenv("TLD_DW_STREAM") && atoi(getenv("TLD_DW_STREAM")) == 0);      // A/B knob: the tiled kernel instead
-    if (grid > 16 && grid % 32 == 0 && stream_on) {       // row-streaming variant (ring of image rows in LDS, a DMA wave); halved tables
+    if (grid > 16 && grid % 32 == 0) {       // row-streaming variant (ring of image rows in LDS, a DMA wave); halved tables
         const dim3 gr((unsigned)(batch * (grid / 32) * (channels / DW_CB)));
         if (out8) hipLaunchKernelGGL(dwconv_gelu_stream_kernel<true>, gr, dim3(320), 0, s, in, out, w9c_half, bias_half, batch, grid, channels, out8, scale8);
         else hipLaunchKernelGGL(dwconv_gelu_stream_kernel<false>, gr, dim3(320), 0, s, in, out, w9c_half, bias_half, batch, grid, channels, out8, scale8);

@@ -299,7 +299,7 @@ struct tld_vae {
     // GroupNorm statistics fused into the producing convolution's epilogue: true while gn_partial describes the tensor the
     // next group_norm() normalises (set by conv3x3, consumed / invalidated by group_norm and by anything else that writes x)
     bool have_partial = false;
-    bool fuse_stats = true;               // TLD_VAE_FUSE_STATS=0: always the separate statistics kernel (A/B testing)
+    bool fuse_stats = true;               // GroupNorm statistics in the producing conv epilogue wherever the shapes allow
     bool debug = false;
     std::vector<Stage> stages;
     bool profile = false;
@@ -592,7 +592,7 @@ int tld_vae_create(const tld_vae_config* cfg, tld_vae** out) {
     v->G = cfg->norm_num_groups; v->zc = cfg->latent_channels; v->oc = cfg->out_channels; v->nb = cfg->n_blocks; v->hl = cfg->latent_size;
     v->boc.assign(cfg->block_out_channels, cfg->block_out_channels + cfg->n_blocks);
     v->C0 = v->boc[v->nb - 1];
-    v->fuse_stats = !(getenv("TLD_VAE_FUSE_STATS") && atoi(getenv("TLD_VAE_FUSE_STATS")) == 0);
+    v->fuse_stats = true;
     v->buf_elems = max_act_elems(v) * (size_t)cfg->max_batch;
     const size_t bytes = v->buf_elems * 2 + kHdr;
     if (bytes >= (1ull << 32)) {

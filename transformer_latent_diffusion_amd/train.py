@@ -97,9 +97,16 @@ class Trainer:
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, keep_ema: bool = True, process_group=None):
         self.cfg = denoiser_cfg
         self.tc = train_cfg if train_cfg is not None else TrainConfig()
-        self.device = torch.device(device)
-        if self.device.type != "cuda" or not torch.cuda.is_available():
+        dev = torch.device(device)
+        if dev.type != "cuda" or not torch.cuda.is_available():
             raise RuntimeError("Trainer needs a HIP device ('cuda'); the training engine has no CPU path")
+        # ONE device for the engine, the flat tensors and the stream: "cuda" means the caller's CURRENT device (torch.cuda.set_device(local_rank)
+        # under torch.distributed.run), exactly as Denoiser resolves it -- not device 0
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        if float(denoiser_cfg.dropout) != 0.0:
+            # the reference trains with model.train(): dropout_p in SDPA and nn.Dropout in the MLP (tld/transformer_blocks.py:43,105).  The engine's
+            # training forward has no dropout; training a different model silently is worse than refusing (every published config has dropout = 0)
+            raise NotImplementedError(f"DenoiserConfig.dropout = {denoiser_cfg.dropout}: the training engine implements dropout = 0 only")
         self.betas, self.eps = betas, eps
         self.group = process_group
         self.layout = param_layout(denoiser_cfg)
@@ -108,7 +115,7 @@ class Trainer:
         L = _lib.lib()
         self.max_batch = int(max_batch if max_batch is not None else self.tc.batch_size)
         cc = _lib.TldConfig(c["image_size"], c["noise_embed_dims"], c["patch_size"], c["embed_dim"], c["n_layers"], c["text_emb_size"],
-                            c["n_channels"], c["mlp_multiplier"], self.max_batch, self.device.index or 0)
+                            c["n_channels"], c["mlp_multiplier"], self.max_batch, self.device.index)
         h = C.c_void_p()
         _lib.check(L.tld_train_create(C.byref(cc), C.byref(h)), "tld_train_create")
         self._h = h
@@ -222,9 +229,12 @@ class Trainer:
             raise ValueError("inconsistent batch shapes")
         if B > self.max_batch:
             raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
-        def launch(xn_, nl_, lab_, tgt_, pred_):
+        def launch(xn_, nl_, lab_, tgt_, pred_, refresh=False):
             stream = torch.cuda.current_stream(dev).cuda_stream
             with torch.cuda.device(dev):
+                if refresh:     # graph capture: the bf16 / transposed operand copies are rebuilt INSIDE the captured region, whatever the engine's
+                    # weights_fresh flag says at capture time -- every replay then follows the optimizer's latest parameters
+                    _lib.check(_lib.lib().tld_train_refresh_weights(self._h, C.c_void_p(stream)), "tld_train_refresh_weights")
                 _lib.check(_lib.lib().tld_train_forward_backward(self._h, C.c_void_p(xn_.data_ptr()), C.c_void_p(nl_.data_ptr()), C.c_void_p(lab_.data_ptr()),
                                                                  C.c_void_p(tgt_.data_ptr()), B, C.c_void_p(self._loss.data_ptr()), C.c_void_p(pred_.data_ptr()),
                                                                  C.c_void_p(stream)), "tld_train_forward_backward")
@@ -238,13 +248,13 @@ class Trainer:
                     torch.cuda.synchronize(dev)
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        launch(*self._static)
+                        launch(*self._static, refresh=True)
                     self._graph = g
                 else:
                     for dst, src in zip(self._static[:4], (xn, nl, lab, tgt)):
                         dst.copy_(src)
                 self._graph.replay()
-                return self._loss, self._static[4]
+                return self._loss, self._static[4].clone()         # (a copy: the static buffer is overwritten by the next replay)
         pred = torch.empty_like(xn)
         launch(xn, nl, lab, tgt, pred)
         return self._loss, pred
@@ -269,8 +279,60 @@ class Trainer:
         self.optimizer_step()
         return loss
 
+    # ---- checkpoint / resume ----------------------------------------------------------------------------------------------------
+    def optimizer_state_dict(self) -> Dict[str, object]:
+        """``torch.optim.Adam(model.parameters(), lr).state_dict()`` as the reference saves it (tld/train.py:86,152): per-parameter
+        ``{step, exp_avg, exp_avg_sq}`` in ``named_parameters()`` order + one param group.  (Before the first step torch's ``state`` is empty.)"""
+        state = {}
+        if self.step > 0:
+            for i, (k, (o, s)) in enumerate(self.layout.items()):
+                n = int(np.prod(s))
+                state[i] = {"step": torch.tensor(float(self.step)), "exp_avg": self.exp_avg[o:o + n].view(*s).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[o:o + n].view(*s).clone()}
+        group = {"lr": self.tc.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(self.layout)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, osd: Mapping[str, object]) -> None:
+        """Inverse of ``optimizer_state_dict`` (``optimizer.load_state_dict`` of tld/train.py:100): also accepts a reference checkpoint's Adam state."""
+        state = osd.get("state", {})
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+        steps = set()
+        for i, (k, (o, s)) in enumerate(self.layout.items()):
+            st = state.get(i, state.get(str(i)))
+            if st is None:
+                continue
+            n = int(np.prod(s))
+            for name, flat in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+                t = torch.as_tensor(st[name]).detach().to(torch.float32)
+                if tuple(t.shape) != s:
+                    raise RuntimeError(f"optimizer state of parameter {i} ({k}): shape {tuple(t.shape)}, expected {s}")
+                flat[o:o + n].copy_(t.reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise RuntimeError(f"per-parameter Adam step counts differ ({sorted(steps)}): the fused optimizer kernel keeps one count")
+        self.step = steps.pop() if steps else 0
+        groups = osd.get("param_groups") or []
+        if groups:
+            self.tc.lr = float(groups[0].get("lr", self.tc.lr))
+            self.betas = tuple(groups[0].get("betas", self.betas)); self.eps = float(groups[0].get("eps", self.eps))
+
     def checkpoint(self) -> Dict[str, object]:
-        """The dict the reference saves (tld/train.py:150-156): EMA weights, optimizer state, global step."""
-        return {"model_ema": self.ema_state_dict(),
-                "opt_state": {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.step, "lr": self.tc.lr},
-                "global_step": self.step}
+        """The dict the reference saves (tld/train.py:150-156): EMA weights, ``optimizer.state_dict()``, global step."""
+        return {"model_ema": self.ema_state_dict(), "opt_state": self.optimizer_state_dict(), "global_step": self.global_step}
+
+    @property
+    def global_step(self) -> int:
+        return self.step
+
+    def load_checkpoint(self, ckpt) -> "Trainer":
+        """Resume as the reference does with ``from_scratch=False`` (tld/train.py:92-104): the EMA weights go into the live model (and the EMA
+        copy restarts from them), the optimizer state and the step count are restored.  ``ckpt``: the dict, or a path to a torch-saved one."""
+        if isinstance(ckpt, (str, os.PathLike)):
+            ckpt = torch.load(ckpt, map_location="cpu", weights_only=False)
+        sd = {k.replace("_orig_mod.", "").replace("module.", ""): v for k, v in ckpt["model_ema"].items()}
+        self.load_state_dict(sd)
+        self.load_optimizer_state_dict(ckpt["opt_state"])
+        if "global_step" in ckpt and int(ckpt["global_step"]) != self.step and self.step == 0:
+            self.step = int(ckpt["global_step"])
+        return self
