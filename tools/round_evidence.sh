@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box call that refreshes the evidence of a round under gpurun_out/<tag> (copied into profiles/ afterwards):
-# full GPU suite, PMC traffic (C1), bench lines C1 (with cpu_baseline) / C3 / C4 bf16 / C4 fp8, rocprofv3 kernel stats, parity report.
-T=${1:-r03}; P=${2:-r03}      # tag under gpurun_out, file prefix under profiles/
+# full GPU suite, PMC traffic (C1), bench lines C1 (with cpu_baseline) / C3 / C4 bf16 / C4 fp8 (8 images per GPU), rocprofv3 kernel stats, parity report.
+T=${1:-r04}; P=${2:-r04}      # tag under gpurun_out, file prefix under profiles/
 O=gpurun_out/$T
 mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests.log
@@ -10,12 +10,12 @@ bash tools/pmc_traffic.sh $O/pmc > $O/pmc.log 2>&1; tail -6 $O/pmc.log
 cp $O/pmc/traffic.json profiles/${P}_pmc_traffic.json 2>/dev/null
 timeout 900 python bench.py --steps 5 --warmup 2 --with-vae > $O/bench_c1.json 2> $O/bench_c1.err; cut -c1-300 $O/bench_c1.json; grep -o '"with_vae".*' $O/bench_c1.json | cut -c1-400
 timeout 300 python bench.py --image-size 64 --images-per-gpu 16 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c3.json 2> $O/bench_c3.err; cut -c1-200 $O/bench_c3.json
-timeout 300 python bench.py --image-size 128 --images-per-gpu 4 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c4_bf16.json 2> $O/bench_c4_bf16.err; cut -c1-200 $O/bench_c4_bf16.json
-timeout 300 python bench.py --image-size 128 --images-per-gpu 4 --steps 2 --warmup 1 --no-cpu-baseline --gemm-dtype fp8 > $O/bench_c4_fp8.json 2> $O/bench_c4_fp8.err; cut -c1-200 $O/bench_c4_fp8.json
+timeout 300 python bench.py --image-size 128 --images-per-gpu 8 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c4_bf16.json 2> $O/bench_c4_bf16.err; cut -c1-200 $O/bench_c4_bf16.json
+timeout 300 python bench.py --image-size 128 --images-per-gpu 8 --steps 2 --warmup 1 --no-cpu-baseline --gemm-dtype fp8 > $O/bench_c4_fp8.json 2> $O/bench_c4_fp8.err; cut -c1-200 $O/bench_c4_fp8.json
 R=$(pwd); cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c1 -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $R/$O/prof_c1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c3 -o p -- python $R/bench.py --image-size 64 --images-per-gpu 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile > $R/$O/prof_c3.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c4f -o p -- python $R/bench.py --image-size 128 --images-per-gpu 4 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --gemm-dtype fp8 > $R/$O/prof_c4f.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof_c4f -o p -- python $R/bench.py --image-size 128 --images-per-gpu 8 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --gemm-dtype fp8 > $R/$O/prof_c4f.log 2>&1
 cd $R
 python profiles/summarize_rocpd.py $O/prof_c1/p_results.db $O/c1_kernel_stats.csv > /dev/null 2>&1; head -12 $O/c1_kernel_stats.csv | cut -c1-150
 python profiles/summarize_rocpd.py $O/prof_c3/p_results.db $O/c3_kernel_stats.csv > /dev/null 2>&1

@@ -428,6 +428,7 @@ bool cross_row_supports_ln3_stats(int d);
 struct TailParams {
     const resid_t* tok;           // [B*N, d]
     const float* w;               // [pd, d]
+    const bf16* w_hl;             // optional [2][pd][d]: w split into bf16 hi | lo halves (matrix-pipe form of the kernel; null: VALU form)
     const float* b;               // [pd]
     float* out;                   // [B,C,S,S] fp32
     int batch, C, S, p, grid, pd, d, ntok;

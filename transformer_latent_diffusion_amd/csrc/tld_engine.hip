@@ -110,6 +110,7 @@ struct tld_engine {
     float *conv_w = nullptr, *conv_b = nullptr, *pln1_w = nullptr, *pln1_b = nullptr, *plin_wt = nullptr,
           *plin_b = nullptr, *pln2_w = nullptr, *pln2_b = nullptr, *pos = nullptr, *out_w = nullptr,
           *out_b = nullptr;
+    bf16* out_w_hl = nullptr;           // out_proj weight as a split bf16 pair [2][pd][d] (tail_mfma_kernel)
     std::vector<Layer> layers;
     const float **tab_kv_w = nullptr, **tab_q_w = nullptr, **tab_n2_w = nullptr, **tab_n2_b = nullptr;   // [L] device tables
 
@@ -432,7 +433,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
     {
         ProfScope ps(e, KC_TAIL, s);
         TailParams tp{};
-        tp.tok = e->x; tp.w = e->out_w; tp.b = e->out_b; tp.out = out; tp.batch = batch;
+        tp.tok = e->x; tp.w = e->out_w; tp.w_hl = e->out_w_hl; tp.b = e->out_b; tp.out = out; tp.batch = batch;
         tp.C = e->cfg.n_channels; tp.S = e->cfg.image_size; tp.p = e->cfg.patch_size; tp.grid = e->grid;
         tp.pd = e->pd; tp.d = d; tp.ntok = e->ntok;
         launch_tail(tp, s);
@@ -556,6 +557,18 @@ int tld_engine_finalize_weights(tld_engine* e) {
     UP32("denoiser_trans_block.out_proj.0.weight", out_w, pd * d)
     UP32("denoiser_trans_block.out_proj.0.bias", out_b, pd)
 #undef UP32
+    {   // out_proj weight as hi + lo bf16 halves for the matrix-pipe tail kernel (hi = bf16(w), lo = bf16(w - hi): 16 significant bits)
+        const std::vector<float>& W = e->host["denoiser_trans_block.out_proj.0.weight"].data;
+        std::vector<uint16_t> hl((size_t)(2 * pd * d));
+        for (int64_t i = 0; i < pd * d; ++i) {
+            const uint16_t hi = f32_to_bf16_rne(W[(size_t)i]);
+            uint32_t u = (uint32_t)hi << 16; float hf; memcpy(&hf, &u, 4);
+            hl[(size_t)i] = hi; hl[(size_t)(pd * d + i)] = f32_to_bf16_rne(W[(size_t)i] - hf);
+        }
+        if (int rc = dev_alloc(e, &e->out_w_hl, hl.size())) return rc;
+        HIP_TRY(hipMemcpy(e->out_w_hl, hl.data(), hl.size() * 2, hipMemcpyHostToDevice));
+        e->weight_bytes += (int64_t)hl.size() * 2;
+    }
     {   // Linear(pd -> d) weight [d, pd] -> transposed [pd, d] for coalesced per-feature reads
         const char* key = "denoiser_trans_block.patchify_and_embed.3.weight";
         auto it = e->host.find(key);

@@ -91,7 +91,8 @@ struct G256P : G256<BN> {
     static constexpr int CB2_OFF = ROWSTAT2_OFF + 256 * 8;          // c1 | bias of the tile's 256 columns (fp32)
     static constexpr int UPDW2_LDS = CB2_OFF + 2048;
     static constexpr int PLAINRS_OFF = LDS_BYTES;    // EPI_BIAS_BF16 with folded LayerNorm-3: the tile's 256 (mean, rstd) pairs
-    static constexpr int PLAINLN_LDS = LDS_BYTES + 256 * 8;
+    static constexpr int PLAINCB_OFF = PLAINRS_OFF + 256 * 8;       // ... and c1 | bias of the tile's columns (fp32; bf16 operands, no conv)
+    static constexpr int PLAINLN_LDS = PLAINCB_OFF + 2048;
     static constexpr int SCRATCH = 4608;             // per-wave epilogue scratch (8 x 4608 <= one stage)
     // EPI_QKV_ATTN (BN = 192): stage 0 keeps receiving the next tile's first K-step while the epilogue runs; the head's K, V^T and Q
     // images live behind it (stage 1, which a tile of an even number of K-steps consumes last, the LayerNorm side tables -- dead once the
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     constexpr int SC_OFF = G::LDS_BYTES;                                // F8: [stage][A scales 1 KiB | W scales 1 KiB] behind the stages
     static_assert(!F8 || (EPI == EPI_F32 || EPI == EPI_QKV || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID), "fp8 epilogues");
     static_assert(!CONV || (!F8 && (EPI == EPI_F32 || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID)), "conv mode");
+    constexpr bool PLAIN_CB = EPI == EPI_BIAS_BF16 && BN != 384 && !F8 && !CONV;       // bias / c1 of the tile's columns staged in LDS (see aux_dma)
     constexpr bool IS_QKV = EPI == EPI_QKV || EPI == EPI_QKV_LN, LN = EPI == EPI_QKV_LN || EPI == EPI_QKV_ATTN;
     static_assert(EPI != EPI_QKV_ATTN || (BN == 192 && !F8 && !CONV && !RING), "the fused attention epilogue is written for 256 x 192 tiles");
     static_assert(EPI != EPI_QKV_ATTN || G::ATTN_LDS <= 160 * 1024, "LDS");
@@ -475,6 +477,16 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     const char* src = reinterpret_cast<const char*>(p.row_stats + r0s);
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::PLAINRS_OFF + wid * 1024), 16, 0, 0);
                 }
+                // the tile's bias (and LayerNorm-3 column sums) by DMA as well: as global loads inside the store loop they queued behind the previous
+                // 32-row slab's stores (vmcnt retires in order), i.e. every slab waited for the stores of the one before
+                if constexpr (PLAIN_CB) {
+                    if (wid == 3 || (wid == 2 && p.row_stats)) {
+                        int col = n0 + lane * 4;
+                        col = col < p.N ? col : 0;
+                        const float* src = (wid == 2 ? p.ln_c1 : p.bias) + col;
+                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + G::PLAINCB_OFF + (wid - 2) * 1024), 16, 0, 0);
+                    }
+                }
             }
             if constexpr (EPI == EPI_UP_DWCONV2) {
                 constexpr int RS_OFF = G::ROWSTAT2_OFF;
@@ -520,11 +532,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             //   free for DMA as soon as that barrier is passed; every wave waits for its own DMA pieces (vmcnt 0) before
             //   the last barrier of a K-step, which both groups pass before anyone reads the next stage.
             const int grp = wid >> 2;
-            wait_vmcnt<0>();                       // first K-step of the tile landed (own pieces) ...
+            wait_vmcnt<0>();                       // first K-step of the tile landed (own pieces) ...  (skipping this wait for tiles whose first K-step was waited for in the previous tile's last step -- it then only covers that tile's output stores -- measured neutral: kept)
             __builtin_amdgcn_s_barrier();          // ... everybody's; also: the previous epilogue's scratch reads are done
             if (grp) __builtin_amdgcn_s_barrier(); // stagger in
             for (int k = 0; k < nk; ++k, ++g) {
-                if (k == 1) aux_dma();
+                if (k == (nk > 1 ? 1 : 0)) aux_dma();        // (K = 64: the tile's only K-step; every wave is past the previous epilogue since the barrier above)
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
                 const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV2);
@@ -834,6 +846,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 }
                 __builtin_amdgcn_s_barrier();
                 if (!TLD_EPI_BIT(4)) {
+                    // (round 4, both measured and dropped: these 13 loads hoisted above the image write -- 20 spilled registers, 188 -> 198 us -- and the
+                    // same constants staged in LDS by DMA with the side tables -- neutral, 185.5 vs 185.4 us: their latency is not what this phase waits for)
                     const int cq = threadIdx.x & 63;                     // channel quad
                     const int c0 = n0 + cq * 4;
                     u32x4 WA[3], WB[3], WC[3], WD[3];                    // packed bf16 weight pairs, 4 channels each
@@ -913,6 +927,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 #pragma unroll
                     for (int j = 0; j < G::TN; ++j) { gsum[j] = 0.f; gsq[j] = 0.f; }
                 }
+                // the residual values of sub-tile (i, j + 1) are fetched while (i, j) goes through the LDS transpose: each of the TM x TN sub-tiles used
+                // to expose one global-load latency (every workgroup of the one-round down projection at the same moment)
+                // (one buffer of four 8-byte values: each is reloaded for the next sub-tile right after it has been consumed -- a second buffer
+                // pushed the 384-wide kernel, 192 accumulator registers, into spills inside its K loop)
+                resid4_t rnx[4];
+                auto rfetch1 = [&](int i2, int j2, int itr) {
+                    const int idx = itr * 64 + lane;
+                    const int row = row0 + i2 * 32 + (idx >> 3), col = col0 + j2 * 32 + (idx & 7) * 4;
+                    if (row < p.M && col < p.N && !TLD_EPI_BIT(16)) rnx[itr] = rs_raw4(p.resid + (size_t)row * p.ldr + col);
+                    else rnx[itr] = resid4_t{};
+                };
+#pragma unroll
+                for (int itr = 0; itr < 4; ++itr) rfetch1(0, 0, itr);
 #pragma unroll
                 for (int i = 0; i < G::TM; ++i) {
                     float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};   // row partials of the new residual
@@ -936,7 +963,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             const int row = row0 + i * 32 + rl, col = col0 + j * 32 + ch * 4;
                             if (row < p.M && col < p.N) {
                                 resid_t* px = p.resid + (size_t)row * p.ldr + col;
-                                float4 o = TLD_EPI_BIT(16) ? make_float4(0.f, 0.f, 0.f, 0.f) : rs_load4(px);      // (attribution builds only)
+                                float4 o = rs_widen4(rnx[itr]);
                                 o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
                                 if (!TLD_EPI_BIT(1)) rs_store4(px, o);
                                 if constexpr (CONV) {
@@ -950,6 +977,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                     pq[itr] = fmaf(r0, r0, fmaf(r1, r1, fmaf(r2, r2, fmaf(r3, r3, pq[itr]))));
                                 }
                             }
+                            if (j + 1 < G::TN) rfetch1(i, j + 1, itr); else if (i + 1 < G::TM) rfetch1(i + 1, 0, itr);
                         }
                     }
                     if constexpr (G::WCOLS == 96) {
@@ -1180,10 +1208,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                                 float rs_ = 1.0f;
                                 if constexpr (EPI == EPI_BIAS_BF16) {
                                     const int cg = col0 + cl < p.N ? col0 + cl : 0;
-                                    bv = *reinterpret_cast<const float4*>(p.bias + cg);
+                                    const int ct = wn * G::WCOLS + cl;                  // column inside the tile
+                                    if constexpr (PLAIN_CB) bv = *reinterpret_cast<const float4*>(smem + G::PLAINCB_OFF + 1024 + ct * 4);
+                                    else bv = *reinterpret_cast<const float4*>(p.bias + cg);
                                     if (p.row_stats) {      // LayerNorm-3 folded in: rstd_m (acc - mean_m c1[n]) + b1[n], lane = token row
                                         const float2 st2 = *reinterpret_cast<const float2*>(smem + G::PLAINRS_OFF + (wm * G::WROWS + i * 32 + e_l31) * 8);
-                                        const float4 c4 = *reinterpret_cast<const float4*>(p.ln_c1 + cg);
+                                        const float4 c4 = PLAIN_CB ? *reinterpret_cast<const float4*>(smem + G::PLAINCB_OFF + ct * 4) : *reinterpret_cast<const float4*>(p.ln_c1 + cg);
                                         rs_ = st2.y;
                                         const float nm_ = -st2.y * st2.x;
                                         bv.x = fmaf(nm_, c4.x, bv.x); bv.y = fmaf(nm_, c4.y, bv.y);

@@ -499,10 +499,9 @@ __global__ __launch_bounds__(512) void cross_row_mfma_kernel(CrossRowParams p, i
     const size_t ibase = p.x_in ? (size_t)(b % p.src_batch) * p.ntok : obase;
 
     auto pair_row = [&](int g) { return 16 * (g0 + g) + 2 * wid; };   // this wave's row pair of group g (row inside the sample)
-    // two row pairs in flight per wave behind the one being processed (16 waves x 12 KB = 96 KB per CU: with one pair the kernel sat at
-    // Little's-law parity with the HBM latency): buffers A and B alternate between even and odd groups
-    resid4_t xrA[2][NQ], xrB[2][NQ];
-    bf16x4 arA[2][NQ], arB[2][NQ];
+    // the next row pair's loads are in flight while the current one is processed (a second pair in flight measured 1 us SLOWER: 40.8 vs 39.7)
+    resid4_t xr[2][NQ];
+    bf16x4 ar[2][NQ];
     auto fetch = [&](size_t row, resid4_t (&xv)[NQ], bf16x4 (&av)[NQ]) {
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
@@ -511,12 +510,8 @@ __global__ __launch_bounds__(512) void cross_row_mfma_kernel(CrossRowParams p, i
             av[j] = *reinterpret_cast<const bf16x4*>(p.att + row * d + n);
         }
     };
-    fetch(ibase + pair_row(0), xrA[0], arA[0]);
-    fetch(ibase + pair_row(0) + 1, xrA[1], arA[1]);
-    if (groups_per_wg > 1) {
-        fetch(ibase + pair_row(1), xrB[0], arB[0]);
-        fetch(ibase + pair_row(1) + 1, xrB[1], arB[1]);
-    }
+    fetch(ibase + pair_row(0), xr[0], ar[0]);
+    fetch(ibase + pair_row(0) + 1, xr[1], ar[1]);
 
     const int tok = lane & 15, kq = lane >> 4;                       // MFMA roles: row of an operand / output column, and k-quarter / head quad
     // A operand (rows = heads), this wave's K slice, split hi / lo: K-block kb = wid NQ + s2 covers features 32 kb .. 32 kb + 31, of which this
@@ -551,7 +546,7 @@ __global__ __launch_bounds__(512) void cross_row_mfma_kernel(CrossRowParams p, i
     for (int j = 0; j < NQ; ++j) bwl[j] = p.bwq[(size_t)tl * H + 4 * j + (lane >> 4)] - p.bwq[(size_t)tn * H + 4 * j + (lane >> 4)];
     const bool fold3 = p.ln3_stats != nullptr;
 
-    auto step = [&](int g, resid4_t (&xr)[2][NQ], bf16x4 (&ar)[2][NQ]) {
+    for (int g = 0; g < groups_per_wg; ++g) {
         // ---- phase A: the wave's row pair -> x1, LayerNorm-2 statistics, centred split-bf16 rows into the tile
         f32x4 v[2][NQ];                                              // x1 = x + att, fp32
 #pragma unroll
@@ -564,9 +559,9 @@ __global__ __launch_bounds__(512) void cross_row_mfma_kernel(CrossRowParams p, i
                 v[u][j][2] = xw.z + (float)ar[u][j][2];
                 v[u][j][3] = xw.w + (float)ar[u][j][3];
             }
-        if (g + 2 < groups_per_wg) {
-            fetch(ibase + pair_row(g + 2), xr[0], ar[0]);
-            fetch(ibase + pair_row(g + 2) + 1, xr[1], ar[1]);
+        if (g + 1 < groups_per_wg) {
+            fetch(ibase + pair_row(g + 1), xr[0], ar[0]);
+            fetch(ibase + pair_row(g + 1) + 1, xr[1], ar[1]);
         }
         const size_t row = obase + pair_row(g);
         if (p.sa_out) {
@@ -685,10 +680,6 @@ __global__ __launch_bounds__(512) void cross_row_mfma_kernel(CrossRowParams p, i
                 }
             }
         }
-    };
-    for (int g = 0; g < groups_per_wg; g += 2) {
-        step(g, xrA, arA);
-        if (g + 1 < groups_per_wg) step(g + 1, xrB, arB);
     }
 }
 
@@ -765,6 +756,80 @@ __global__ __launch_bounds__(256) void tail_kernel(TailParams p, int rows_per_bl
         }
     }
 }
+
+#ifdef TLD_RESID_BF16
+// ------------------------------------------------------------------------------------------------
+// out_proj + unpatchify on the matrix pipe (round 4; bf16 residual stream, pd d <= 40960).  The VALU kernel above spends a wave-wide
+// reduction per (row, output feature) -- 16 per row at the 100 M model -- and was a 43 us latency chain per forward for 2 MFLOP per row.
+// Here D[feature][token] = W[pd x d] . x[16 tokens x d]^T per wave as d / 32 v_mfma_f32_16x16x32_bf16 steps per 16-feature tile: the token
+// rows are ALREADY the operand format (bf16, feature-contiguous: lane (token, k-quarter) loads its 16 bytes straight from the residual
+// stream), the weights sit in LDS as a split bf16 pair (hi + lo: fp32-grade products, same trick as cross_row's logits), accumulation fp32.
+// A lane ends with 4 consecutive output features of its token: bias, then the pixel-shuffle store (tld/denoiser.py:47-52,72,82).
+template <int NT>       // 16-feature tiles covering patch_dim (1 .. 4)
+__global__ __launch_bounds__(256) void tail_mfma_kernel(TailParams p, const bf16* __restrict__ whl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int d = p.d, PITCH = d * 2, pdp = NT * 16;
+    char* wh = smem;                                  // [pdp][PITCH] hi halves (rows >= pd: zeros), chunk c of row r at chunk c ^ (r & 15)
+    char* wl = smem + pdp * PITCH;                    // lo halves
+    const int chunks = d >> 3;
+    for (int i = threadIdx.x; i < 2 * pdp * chunks; i += 256) {
+        const int plane = i / (pdp * chunks), rem = i - plane * pdp * chunks;
+        const int r = rem / chunks, c = rem - r * chunks;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r < p.pd) v = *reinterpret_cast<const u32x4*>(whl + ((size_t)plane * p.pd + r) * d + c * 8);
+        *reinterpret_cast<u32x4*>((plane ? wl : wh) + r * PITCH + ((c ^ (r & 15)) << 4)) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int tok = lane & 15, kq = lane >> 4;
+    const int total = p.batch * p.ntok;
+    const int row0 = (blockIdx.x * 4 + wid) * 16;
+    if (row0 >= total) return;
+    const int row = row0 + tok < total ? row0 + tok : total - 1;
+    const bf16* xrow = p.tok + (size_t)row * d + kq * 8;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkb = d >> 5;
+    // token fragments eight K-blocks ahead of their use (the loop is one dependent MFMA chain per tile: what it must hide is the loads)
+    constexpr int PF = 8;
+    bf16x8 xf[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(xrow + (i < nkb ? i : 0) * 32);
+    for (int kb0 = 0; kb0 < nkb; kb0 += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int kb = kb0 + i;
+            if (kb >= nkb) break;
+            const bf16x8 xb = xf[i];
+            if (kb + PF < nkb) xf[i] = *reinterpret_cast<const bf16x8*>(xrow + (kb + PF) * 32);
+            const int chunk = 4 * kb + kq;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int r = t * 16 + tok;
+                const int off = r * PITCH + ((chunk ^ (r & 15)) << 4);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wh + off), xb, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(wl + off), xb, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    if (row0 + tok >= total) return;
+    const int b = row / p.ntok, tk = row - b * p.ntok;
+    const int ti = tk / p.grid, tj = tk - ti * p.grid;
+    const int pp = p.p * p.p;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = t * 16 + 4 * kq + r;              // feature f = (c, u, v) of token (ti, tj) -> out[b, c, ti*p+u, tj*p+v]
+            if (f < p.pd) {
+                const int c = f / pp, uv = f - c * pp;
+                const int u = uv / p.p, vv = uv - u * p.p;
+                p.out[(((size_t)b * p.C + c) * p.S + (ti * p.p + u)) * p.S + (tj * p.p + vv)] = acc[t][r] + p.b[f];
+            }
+        }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void update_kernel(UpdateParams p) {
@@ -1047,8 +1112,8 @@ bool cross_row_supports_ln3_stats(int d) { return d == 768 || d == 512 || d == 2
 
 void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
     if (p.d % 256 == 0 && p.d <= 1024 && p.ntok % 16 == 0) {
-        // 512-thread workgroups over 16-row groups of one sample, ONE per CU (the kernel holds ~190 registers at d = 768: the split-bf16 slices of
-        // the query-difference vectors and two prefetched row pairs live in registers; two workgroups per CU at 128 registers spilled and ran
+        // 512-thread workgroups over 16-row groups of one sample, ONE per CU (the kernel holds ~170 registers at d = 768: the split-bf16 slices of
+        // the query-difference vectors and the prefetched row pair live in registers; two workgroups per CU at 128 registers spilled and ran
         // 43.7 us against 38.0).  Groups per workgroup: the largest power of two (<= 16) that divides a sample's groups and still leaves >= 1
         // workgroup per CU (at C1: 128 samples x 16 groups / 8 = 256 workgroups = one resident round)
         const int gps = p.ntok / 16;
@@ -1078,6 +1143,18 @@ void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
 }
 
 void launch_tail(const TailParams& p, hipStream_t s) {
+#ifdef TLD_RESID_BF16
+    if (p.w_hl && p.d % 128 == 0 && (long)p.pd * p.d <= 40960) {      // matrix-pipe form: split-bf16 weights [2][pd][d] in <= 160 KiB of LDS (the XOR swizzle of its
+                                                                      // weight image permutes 16-byte chunks within aligned groups of 16: rows of d / 8 = 16 k chunks)
+        const int nt = (p.pd + 15) / 16, rows = p.batch * p.ntok;
+        const int lds = 2 * nt * 16 * p.d * 2;
+        dim3 grid((unsigned)((rows + 63) / 64));
+#define TLD_TM(NT) do { TLD_LDS_OPT_IN((tail_mfma_kernel<NT>), lds); hipLaunchKernelGGL((tail_mfma_kernel<NT>), grid, dim3(256), lds, s, p, p.w_hl); } while (0)
+        if (nt == 1) TLD_TM(1); else if (nt == 2) TLD_TM(2); else if (nt == 3) TLD_TM(3); else TLD_TM(4);
+#undef TLD_TM
+        return;
+    }
+#endif
     const int rpb = 64;
     const int rows = p.batch * p.ntok;
     const int lds = p.pd * p.d * (int)sizeof(float);
