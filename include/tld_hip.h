@@ -255,6 +255,16 @@ TLD_API int tld_train_refresh_weights(tld_train* e, void* hip_stream);
  * fp32[1]) and the prediction to pred_out (device fp32 [batch, C, S, S]). */
 TLD_API int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* noise_level, const float* label, const float* target,
                                        int32_t batch, float* loss_out, float* pred_out, void* hip_stream);
+/* The same step with a host callback for overlapping the data-parallel gradient reduction with the backward pass -- what the bucketed
+ * all-reduce hooks of the reference's DDP wrapper do (accelerate.prepare -> torch DDP, tld/train.py:109,168).  grad_ready(user, offset,
+ * numel) is invoked on the calling thread each time the kernels that FINISH a contiguous range [offset, offset + numel) of the flat
+ * gradient vector have been enqueued on hip_stream: once per decoder block, last block first (a block's 15 tensors are contiguous in
+ * named_parameters() order), then the ranges before and after the blocks (embedding / position table; out_proj, norm, label_proj --
+ * final only at the end of the backward).  The ranges tile the vector exactly.  The callback typically records an event on hip_stream
+ * and launches an asynchronous all-reduce of that slice on a second stream; it must not synchronise hip_stream.  NULL: no callbacks. */
+typedef void (*tld_grad_ready_fn)(void* user, int64_t offset, int64_t numel);
+TLD_API int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const float* noise_level, const float* label, const float* target,
+                                          int32_t batch, float* loss_out, float* pred_out, void* hip_stream, tld_grad_ready_fn grad_ready, void* user);
 /* optimizer.step() of torch.optim.Adam(lr) + update_ema(ema_model, model, alpha) -- tld/train.py:87,169,55-58,172.  step counts from 1;
  * ema may be NULL; grad_scale multiplies the gradient first (1 / world_size after a SUM all-reduce). */
 TLD_API int tld_train_adam_ema(tld_train* e, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel,

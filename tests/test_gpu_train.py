@@ -187,7 +187,23 @@ xn = nl.view(-1, 1, 1, 1) * noise + (1 - nl.view(-1, 1, 1, 1)) * x
 sl = slice(r * 4 // w, (r + 1) * 4 // w)
 tr.forward_backward(xn[sl], nl[sl], y[sl], x[sl])
 # gloo moves device tensors through the host; RCCL ("nccl") is what a multi-GPU node uses -- same call
+if w > 1:
+    # overlapped reduction (default): one asynchronous all-reduce per decoder block, last block first, then the two ranges around the blocks;
+    # together they tile the flat gradient vector exactly once
+    sl_ = sorted(tr._slices)
+    assert len(tr._slices) == cfg.n_layers + 2 and len(tr._pending) == cfg.n_layers + 2, tr._slices
+    assert sl_[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(sl_, sl_[1:])) and sl_[-1][0] + sl_[-1][1] == tr.numel, sl_
+    first_blocks = [o for o, n in tr._slices[:cfg.n_layers]]
+    assert first_blocks == sorted(first_blocks, reverse=True), first_blocks
 tr.optimizer_step()
+if w > 1:
+    # the same step with ONE blocking all-reduce after the backward (overlap_allreduce=False) lands on the same parameters, bit for bit
+    tr2 = Trainer(cfg, TrainConfig(lr=3e-4), device=dev, init_seed=3, max_batch=4, overlap_allreduce=False)
+    tr2.forward_backward(xn[sl], nl[sl], y[sl], x[sl])
+    assert not tr2._pending
+    tr2.optimizer_step()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.params, tr2.params), float((tr.params - tr2.params).abs().max())
 torch.save(tr.params.cpu(), {out!r} + f".{{w}}.{{r}}")
 print("rank", r, "done")
 """

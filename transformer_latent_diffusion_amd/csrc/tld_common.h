@@ -381,6 +381,7 @@ struct EmbedParams {
     const float* conv_b;          // [pd]
     const float* ln1_w; const float* ln1_b;   // [pd]
     const float* lin_wt;          // [pd, d]  (transposed nn.Linear weight)
+    const bf16* lin_w_hl;         // optional [2][d][pd]: the nn.Linear weight [d, pd] split into bf16 hi | lo halves (matrix-pipe form; null: VALU form)
     const float* lin_b;           // [d]
     const float* ln2_w; const float* ln2_b;   // [d]
     const float* pos;             // [N, d]

@@ -111,6 +111,7 @@ struct tld_engine {
           *plin_b = nullptr, *pln2_w = nullptr, *pln2_b = nullptr, *pos = nullptr, *out_w = nullptr,
           *out_b = nullptr;
     bf16* out_w_hl = nullptr;           // out_proj weight as a split bf16 pair [2][pd][d] (tail_mfma_kernel)
+    bf16* plin_w_hl = nullptr;          // patch-embedding Linear weight as a split bf16 pair [2][d][pd] (embed_mfma_kernel)
     std::vector<Layer> layers;
     const float **tab_kv_w = nullptr, **tab_q_w = nullptr, **tab_n2_w = nullptr, **tab_n2_b = nullptr;   // [L] device tables
 
@@ -301,7 +302,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
         ProfScope ps(e, KC_EMBED, s);
         EmbedParams ep{};
         ep.x = x_src; ep.conv_w = e->conv_w; ep.conv_b = e->conv_b; ep.ln1_w = e->pln1_w; ep.ln1_b = e->pln1_b;
-        ep.lin_wt = e->plin_wt; ep.lin_b = e->plin_b; ep.ln2_w = e->pln2_w; ep.ln2_b = e->pln2_b; ep.pos = e->pos;
+        ep.lin_wt = e->plin_wt; ep.lin_w_hl = e->plin_w_hl; ep.lin_b = e->plin_b; ep.ln2_w = e->pln2_w; ep.ln2_b = e->pln2_b; ep.pos = e->pos;
         ep.tok = xe; ep.stats_out = fold1 ? e->ln_stats : nullptr; ep.batch = b0; ep.src_batch = src_batch; ep.C = e->cfg.n_channels;
         ep.S = e->cfg.image_size; ep.p = e->cfg.patch_size; ep.grid = e->grid; ep.pd = e->pd; ep.d = d;
         ep.ntok = e->ntok;
@@ -568,6 +569,20 @@ int tld_engine_finalize_weights(tld_engine* e) {
         if (int rc = dev_alloc(e, &e->out_w_hl, hl.size())) return rc;
         HIP_TRY(hipMemcpy(e->out_w_hl, hl.data(), hl.size() * 2, hipMemcpyHostToDevice));
         e->weight_bytes += (int64_t)hl.size() * 2;
+    }
+    {   // the same split for the patch-embedding Linear weight [d, pd] (embed_mfma_kernel)
+        const std::vector<float>& W = e->host["denoiser_trans_block.patchify_and_embed.3.weight"].data;
+        if ((int64_t)W.size() == d * pd) {
+            std::vector<uint16_t> hl((size_t)(2 * pd * d));
+            for (int64_t i = 0; i < pd * d; ++i) {
+                const uint16_t hi = f32_to_bf16_rne(W[(size_t)i]);
+                uint32_t u = (uint32_t)hi << 16; float hf; memcpy(&hf, &u, 4);
+                hl[(size_t)i] = hi; hl[(size_t)(pd * d + i)] = f32_to_bf16_rne(W[(size_t)i] - hf);
+            }
+            if (int rc = dev_alloc(e, &e->plin_w_hl, hl.size())) return rc;
+            HIP_TRY(hipMemcpy(e->plin_w_hl, hl.data(), hl.size() * 2, hipMemcpyHostToDevice));
+            e->weight_bytes += (int64_t)hl.size() * 2;
+        }
     }
     {   // Linear(pd -> d) weight [d, pd] -> transposed [pd, d] for coalesced per-feature reads
         const char* key = "denoiser_trans_block.patchify_and_embed.3.weight";

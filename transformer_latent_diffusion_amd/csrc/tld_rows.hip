@@ -759,6 +759,187 @@ __global__ __launch_bounds__(256) void tail_kernel(TailParams p, int rows_per_bl
 
 #ifdef TLD_RESID_BF16
 // ------------------------------------------------------------------------------------------------
+// Patch embedding on the matrix pipe (round 4; patch_dim == 16 -- four latent channels in 2 x 2 patches, every published model -- and
+// d % 256 == 0).  embed_kernel above is one latency chain per row (readlane-broadcast taps, four wave-wide reductions): 52 us per forward
+// for 16 K rows.  Here a 4-wave workgroup takes 32 token rows; every lane (token, half) builds its token's conv outputs / LayerNorm(16)
+// values 8 half .. 8 half + 7 in registers -- exactly the K slice the B operand of v_mfma_f32_32x32x16_bf16 wants from it -- as a split
+// bf16 pair, and Linear(16 -> d) is three MFMAs (hi.hi + hi.lo + lo.hi: fp32-grade) per 32-feature tile against the weight image in LDS;
+// wave w owns feature tiles [w d / 128, (w + 1) d / 128), whose accumulators stay in registers through the two-pass LayerNorm(d) (row sums
+// cross the waves through LDS).  Output rows leave as whole 128-byte segments through a per-wave transpose patch.  tld/denoiser.py:34-45,75-77.
+template <int TPW>      // 32-feature tiles per wave: d = 128 TPW, TPW even
+__global__ __launch_bounds__(256) void embed_mfma_kernel(EmbedParams p, const bf16* __restrict__ wl_hl) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int d = TPW * 128, PD = 16, PP = 144;
+    char* wimg = smem;                                            // [2 planes][d][32 B]: Linear weight rows (hi | lo), 16-B chunk c of row f at c ^ ((f >> 3) & 1)
+    float* cw = reinterpret_cast<float*>(smem + 2 * d * 32);      // [16][16] conv weight (row = output)
+    float* red = cw + PD * PD;                                    // [3][4 waves][32 tokens] row partials (sum; centred squares; rounded sum) + [4][32] rounded squares
+    float* vec = red + 4 * 4 * 32;                                // [3][d]: Linear bias, LayerNorm(d) weight and bias (read per feature quad by every token)
+    char* patch = reinterpret_cast<char*>(vec + 3 * d);           // [4 waves][32 tokens][PP] output transpose
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int total = p.batch * p.ntok;
+    const int grow = blockIdx.x * 32 + l31;
+    const int row = grow < total ? grow : total - 1;
+    const int b = row / p.ntok, tk = row - b * p.ntok;
+    const int ti = tk / p.grid, tj = tk - ti * p.grid;
+    // the token's 16 patch inputs, k = (c, u, v)
+    float xin[PD];
+    {
+        const int pp = p.p * p.p;
+        const float* xb = p.x + (size_t)(b % p.src_batch) * p.C * p.S * p.S;
+#pragma unroll
+        for (int k = 0; k < PD; ++k) {
+            const int c = k / pp, uv = k - c * pp, u = uv / p.p, v = uv - u * p.p;
+            xin[k] = xb[((size_t)c * p.S + (ti * p.p + u)) * p.S + (tj * p.p + v)];
+        }
+    }
+    // (the tables are filled AFTER the patch loads were issued: their latency hides under the fill)
+    for (int i = threadIdx.x; i < 2 * d * 2; i += 256) {          // 16-byte chunks: plane, row, chunk
+        const int plane = i / (d * 2), rem = i - plane * d * 2;
+        const int f = rem >> 1, c = rem & 1;
+        *reinterpret_cast<u32x4*>(wimg + plane * d * 32 + f * 32 + ((c ^ ((f >> 3) & 1)) << 4)) =
+            *reinterpret_cast<const u32x4*>(wl_hl + ((size_t)plane * d + f) * PD + c * 8);
+    }
+    if (threadIdx.x < PD * PD) cw[threadIdx.x] = p.conv_w[threadIdx.x];
+    for (int i = threadIdx.x; i < 3 * d / 4; i += 256) {
+        const int which = i / (d / 4), j = i - which * (d / 4);
+        const float* src = which == 0 ? p.lin_b : (which == 1 ? p.ln2_w : p.ln2_b);
+        reinterpret_cast<float4*>(vec)[i] = reinterpret_cast<const float4*>(src)[j];
+    }
+    __syncthreads();
+    // conv outputs o = 8 hi + e, then LayerNorm(16) over the token's 16 outputs (8 here, 8 in lane ^ 32)
+    float pv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int o = 8 * hi + e;
+        const float4* wr = reinterpret_cast<const float4*>(cw + o * PD);
+        float a = p.conv_b[o];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const float4 w4 = wr[k4];
+            a = fmaf(w4.x, xin[4 * k4], a); a = fmaf(w4.y, xin[4 * k4 + 1], a); a = fmaf(w4.z, xin[4 * k4 + 2], a); a = fmaf(w4.w, xin[4 * k4 + 3], a);
+        }
+        pv[e] = a;
+    }
+    auto pair_sum = [&](float v) {          // + the partner lane (same token, other half)
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    };
+    float s8 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s8 += pv[e];
+    const float mean1 = pair_sum(s8) * (1.0f / PD);
+    float q8 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pv[e] -= mean1; q8 = fmaf(pv[e], pv[e], q8); }
+    const float rstd1 = 1.0f / sqrtf(pair_sum(q8) * (1.0f / PD) + kLnEps);
+    bf16x8 bh, bl;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int o = 8 * hi + e;
+        const float pn = pv[e] * rstd1 * p.ln1_w[o] + p.ln1_b[o];
+        bh[e] = (bf16)pn;
+        bl[e] = (bf16)(pn - (float)bh[e]);
+    }
+    // Linear(16 -> d): this wave's TPW feature tiles, D[feature][token]
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int f = 32 * (wid * TPW + t) + l31;
+        const int off = f * 32 + ((hi ^ ((f >> 3) & 1)) << 4);
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wimg + off);
+        const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wimg + d * 32 + off);
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, z, 0, 0, 0);
+        z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, z, 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wlo, bh, z, 0, 0, 0);
+    }
+    // + bias; LayerNorm(d), two passes over the registers; the row's other features live in the partner lane and in the other three waves
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 b4 = *reinterpret_cast<const float4*>(vec + 32 * (wid * TPW + t) + 8 * q + 4 * hi);
+            acc[t][4 * q + 0] += b4.x; acc[t][4 * q + 1] += b4.y; acc[t][4 * q + 2] += b4.z; acc[t][4 * q + 3] += b4.w;
+            s += (acc[t][4 * q + 0] + acc[t][4 * q + 1]) + (acc[t][4 * q + 2] + acc[t][4 * q + 3]);
+        }
+    s = pair_sum(s);
+    if (!hi) red[wid * 32 + l31] = s;
+    __syncthreads();
+    const float mean2 = ((red[l31] + red[32 + l31]) + (red[64 + l31] + red[96 + l31])) * (1.0f / d);
+    float qq = 0.f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] -= mean2; qq = fmaf(acc[t][r], acc[t][r], qq); }
+    qq = pair_sum(qq);
+    if (!hi) red[128 + wid * 32 + l31] = qq;
+    __syncthreads();
+    const float rstd2 = 1.0f / sqrtf(((red[128 + l31] + red[160 + l31]) + (red[192 + l31] + red[224 + l31])) * (1.0f / d) + kLnEps);
+    // affine + position table -> bf16, two tiles (64 features = 128 B per token) at a time through the wave's transpose patch
+    char* T = patch + wid * 32 * PP;
+    float ssum = 0.f, ssq = 0.f;
+    // (the token's position-table values -- the only per-token global loads left in this loop -- are fetched one tile PAIR ahead: as loads
+    // inside the loop they exposed one L2 round trip per feature quad, 24 per lane, and were most of the kernel's first version: 42.6 us)
+    const float* prow = p.pos + (size_t)tk * d + 32 * wid * TPW + 4 * hi;
+    float4 pnx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pnx[i] = *reinterpret_cast<const float4*>(prow + 32 * (i >> 2) + 8 * (i & 3));
+#pragma unroll
+    for (int tp = 0; tp < TPW / 2; ++tp) {
+        float4 pc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pc[i] = pnx[i];
+        if (tp + 1 < TPW / 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) pnx[i] = *reinterpret_cast<const float4*>(prow + 64 * (tp + 1) + 32 * (i >> 2) + 8 * (i & 3));
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int t = 2 * tp + tt;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = 32 * (wid * TPW + t) + 8 * q + 4 * hi;
+                const float4 g4 = *reinterpret_cast<const float4*>(vec + d + n);
+                const float4 c4 = *reinterpret_cast<const float4*>(vec + 2 * d + n);
+                const float4 pe = pc[tt * 4 + q];
+                bf16x4 o;
+                o[0] = (bf16)(acc[t][4 * q + 0] * rstd2 * g4.x + c4.x + pe.x);
+                o[1] = (bf16)(acc[t][4 * q + 1] * rstd2 * g4.y + c4.y + pe.y);
+                o[2] = (bf16)(acc[t][4 * q + 2] * rstd2 * g4.z + c4.z + pe.z);
+                o[3] = (bf16)(acc[t][4 * q + 3] * rstd2 * g4.w + c4.w + pe.w);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float r = (float)o[e]; ssum += r; ssq = fmaf(r, r, ssq); }
+                *reinterpret_cast<bf16x4*>(T + l31 * PP + (tt * 32 + 8 * q + 4 * hi) * 2) = o;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + (lane >> 3), ch = lane & 7;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(T + r * PP + ch * 16);
+            const int gr = blockIdx.x * 32 + r;
+            if (gr < total) *reinterpret_cast<u32x4*>(p.tok + (size_t)gr * d + 32 * (wid * TPW + 2 * tp) + ch * 8) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (p.stats_out) {      // LayerNorm-1 statistics of block 0 (sum, sum of squares of the ROUNDED row), consumed by its QKV GEMM epilogue
+        ssum = pair_sum(ssum); ssq = pair_sum(ssq);
+        if (!hi) { red[256 + wid * 32 + l31] = ssum; red[384 + wid * 32 + l31] = ssq; }
+        __syncthreads();
+        if (wid == 0 && !hi && grow < total) {
+            const float a = (red[256 + l31] + red[288 + l31]) + (red[320 + l31] + red[352 + l31]);
+            const float a2 = (red[384 + l31] + red[416 + l31]) + (red[448 + l31] + red[480 + l31]);
+            *reinterpret_cast<float4*>(p.stats_out + (size_t)grow * kLnSlots) = make_float4(a, a2, 0.f, 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // out_proj + unpatchify on the matrix pipe (round 4; bf16 residual stream, pd d <= 40960).  The VALU kernel above spends a wave-wide
 // reduction per (row, output feature) -- 16 per row at the 100 M model -- and was a 43 us latency chain per forward for 2 MFLOP per row.
 // Here D[feature][token] = W[pd x d] . x[16 tokens x d]^T per wave as d / 32 v_mfma_f32_16x16x32_bf16 steps per 16-feature tile: the token
@@ -1082,6 +1263,17 @@ __global__ __launch_bounds__(256) void dwconv_gelu_tiled_kernel(const bf16* __re
     } while (0)
 
 void launch_embed(const EmbedParams& p, hipStream_t s) {
+#ifdef TLD_RESID_BF16
+    if (p.lin_w_hl && p.pd == 16 && p.C * p.p * p.p == 16 && p.d % 256 == 0 && p.d <= 1024) {       // matrix-pipe form
+        const int rows = p.batch * p.ntok;
+        const int lds = 2 * p.d * 32 + 16 * 16 * 4 + 4 * 4 * 32 * 4 + 3 * p.d * 4 + 4 * 32 * 144;
+        dim3 grid((unsigned)((rows + 31) / 32));
+#define TLD_EM(TPW) do { TLD_LDS_OPT_IN((embed_mfma_kernel<TPW>), lds); hipLaunchKernelGGL((embed_mfma_kernel<TPW>), grid, dim3(256), lds, s, p, p.lin_w_hl); } while (0)
+        if (p.d == 256) TLD_EM(2); else if (p.d == 512) TLD_EM(4); else if (p.d == 768) TLD_EM(6); else TLD_EM(8);
+#undef TLD_EM
+        return;
+    }
+#endif
     const int rows = p.batch * p.ntok;
     const int lds = (p.pd * p.d + p.pd * p.C * p.p * p.p) * (int)sizeof(float);
     TLD_DISPATCH_D(p.d, { TLD_LDS_OPT_IN((embed_kernel<NJ, HALF>), lds); hipLaunchKernelGGL((embed_kernel<NJ, HALF>), dim3((rows + 31) / 32), dim3(256), lds, s, p); });

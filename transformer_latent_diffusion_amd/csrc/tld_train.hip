@@ -287,6 +287,11 @@ int tld_train_refresh_weights(tld_train* e, void* hip_stream) {
 
 int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* noise_level, const float* label, const float* target,
                                int32_t batch, float* loss_out, float* pred_out, void* hip_stream) {
+    return tld_train_forward_backward_cb(e, x_noisy, noise_level, label, target, batch, loss_out, pred_out, hip_stream, nullptr, nullptr);
+}
+
+int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const float* noise_level, const float* label, const float* target,
+                                  int32_t batch, float* loss_out, float* pred_out, void* hip_stream, tld_grad_ready_fn grad_ready, void* user) {
     if (!e || !x_noisy || !noise_level || !label || !target || !loss_out || !pred_out) return tfail(TLD_ERR_INVALID, "null argument");
     if (!e->params) return tfail(TLD_ERR_STATE, "tld_train_bind first");
     if (batch <= 0 || batch > e->B) return tfail(TLD_ERR_INVALID, "batch %d outside [1, max_batch = %d]", batch, e->B);
@@ -471,6 +476,9 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
         weight_grad(e->dsmall, 3 * d, b.a1, d, Gd + p.qkv);
         gemm_bf16(e->dsmall, 3 * d, b.wqkv_t, 3 * d, e->zero_bias, e->dsmall2, M, d, 3 * d, s);         // da1 = dqkv Wqkv
         ln_bwd_rows(e->dsmall2, b.x1, b.st1, P + p.n1w, e->gx, 1, Gd + p.n1w, Gd + p.n1b, M, d);
+        // every gradient of this block is enqueued (its 15 tensors are one contiguous range of the flat vector): the data-parallel
+        // reduction of that slice can start now, under the backward of the blocks below
+        if (grad_ready) grad_ready(user, p.qkv, (p.n3b + d) - p.qkv);
     }
     // ---- patch embedding: x0 = LN2(e) + pos;  e = pn Wlin^T + b;  pn = LN1(p);  p = conv(x)     (tld/denoiser.py:34-45,75-77)
     hipLaunchKernelGGL(pos_grad_kernel, g1((size_t)N * d), blk, 0, s, e->gx, Gd + e->pos, B, N, d);
@@ -494,6 +502,10 @@ int tld_train_forward_backward(tld_train* e, const float* x_noisy, const float* 
     lin_dx(e->dycat, 2 * d, P + e->ff3w, e->dg1, d, B, d, d, 0);
     hipLaunchKernelGGL(mul_gelu_grad, g1((size_t)B * d), blk, 0, s, e->dg1, e->h1, B * d);
     lin_dw(e->dg1, d, e->sinb, e->ne, Gd + e->ff1w, Gd + e->ff1b, B, d, e->ne);
+    if (grad_ready) {       // the ranges around the blocks: conditioning MLP / patch embedding / position table; out_proj, norm, label_proj
+        grad_ready(user, 0, e->lp[0].qkv);
+        grad_ready(user, e->outw, e->nparam - e->outw);
+    }
     HIP_TRY(hipGetLastError());
     return TLD_OK;
 }

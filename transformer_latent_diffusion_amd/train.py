@@ -94,7 +94,8 @@ class Trainer:
 
     def __init__(self, denoiser_cfg: DenoiserConfig, train_cfg: Optional[TrainConfig] = None, device="cuda",
                  state_dict: Optional[Mapping[str, torch.Tensor]] = None, init_seed: int = 0, max_batch: Optional[int] = None,
-                 betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, keep_ema: bool = True, process_group=None):
+                 betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, keep_ema: bool = True, process_group=None,
+                 overlap_allreduce: bool = True):
         self.cfg = denoiser_cfg
         self.tc = train_cfg if train_cfg is not None else TrainConfig()
         dev = torch.device(device)
@@ -137,6 +138,10 @@ class Trainer:
         # static shapes; captured once (on the second full-batch call, after an eager warm-up) and replayed from fixed input buffers, it
         # takes the host out of the loop.  Adam stays outside (its step count is a kernel argument).
         self.use_graph = bool(int(os.environ.get("TLD_TRAIN_GRAPH", "0")))
+        self.overlap_allreduce = overlap_allreduce
+        self._comm_stream = None
+        self._pending = []                # async all-reduce handles of the gradient slices of the step in flight
+        self._slices = []                 # (offset, numel) in the order they became ready (tests)
         self._graph = None
         self._graph_calls = 0
         self._static = None
@@ -229,9 +234,32 @@ class Trainer:
             raise ValueError("inconsistent batch shapes")
         if B > self.max_batch:
             raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
+        overlap = self.overlap_allreduce and self._world() > 1 and not (self.use_graph and B == self.max_batch)
+        self._pending, self._slices = [], []
+        cb = None
+        if overlap:
+            import torch.distributed as dist
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=dev)
+            compute = torch.cuda.current_stream(dev)
+
+            def ready(_user, off, n):      # called by the engine, on this thread, right after the kernels finishing grads[off : off + n] are enqueued
+                ev = torch.cuda.Event()
+                ev.record(compute)
+                self._comm_stream.wait_event(ev)
+                with torch.cuda.stream(self._comm_stream):
+                    self._pending.append(dist.all_reduce(self.grads[off:off + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._slices.append((int(off), int(n)))
+            cb = _lib.GRAD_READY_FN(ready)
+
         def launch(xn_, nl_, lab_, tgt_, pred_, refresh=False):
             stream = torch.cuda.current_stream(dev).cuda_stream
             with torch.cuda.device(dev):
+                if cb is not None:
+                    _lib.check(_lib.lib().tld_train_forward_backward_cb(self._h, C.c_void_p(xn_.data_ptr()), C.c_void_p(nl_.data_ptr()), C.c_void_p(lab_.data_ptr()),
+                                                                        C.c_void_p(tgt_.data_ptr()), B, C.c_void_p(self._loss.data_ptr()), C.c_void_p(pred_.data_ptr()),
+                                                                        C.c_void_p(stream), cb, None), "tld_train_forward_backward_cb")
+                    return
                 if refresh:     # graph capture: the bf16 / transposed operand copies are rebuilt INSIDE the captured region, whatever the engine's
                     # weights_fresh flag says at capture time -- every replay then follows the optimizer's latest parameters
                     _lib.check(_lib.lib().tld_train_refresh_weights(self._h, C.c_void_p(stream)), "tld_train_refresh_weights")
@@ -259,9 +287,20 @@ class Trainer:
         launch(xn, nl, lab, tgt, pred)
         return self._loss, pred
 
+    def _world(self) -> int:
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
     def optimizer_step(self) -> None:
-        """DDP gradient mean (one all-reduce of the flat vector over RCCL) + Adam + EMA (tld/train.py:168-172)."""
-        scale = allreduce_mean_(self.grads, self.group)
+        """DDP gradient mean + Adam + EMA (tld/train.py:168-172).  The gradient sum over the ranks is either already in flight (per-block slices
+        started during the backward, ``overlap_allreduce``) or one all-reduce of the flat vector here."""
+        if self._pending:
+            for w in self._pending:
+                w.wait()                  # the current stream waits for the slice's reduction
+            self._pending = []
+            scale = 1.0 / self._world()
+        else:
+            scale = allreduce_mean_(self.grads, self.group)
         self.step += 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         p = lambda a: C.c_void_p(a.data_ptr()) if a is not None else None
