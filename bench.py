@@ -96,7 +96,7 @@ def physical_cores():
         return max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline(cfg, sd, budget_s=20.0):
+def cpu_baseline(cfg, sd, budget_s=20.0, S=32):
     """The same workload on the host cores, HARD-BOUNDED to about `budget_s` seconds per line.
 
     value: the pure-PyTorch restatement of the module graph (oracle/torch_ref.py -- conv2d / linear / layer_norm /
@@ -113,8 +113,9 @@ def cpu_baseline(cfg, sd, budget_s=20.0):
     levels = schedule.noise_schedule(N_ITER, 1)
     rng = np.random.default_rng(11)
     tm = TorchRefDenoiser(asdict(cfg), sd)
-    b = 8
-    x = torch.from_numpy(rng.standard_normal((b, 4, 32, 32)).astype(np.float32))
+    b = {32: 8, 64: 2}.get(S, 1)               # the same bounded budget at every resolution: fewer images where a forward is 5x / 29x the work
+    gflop_fwd = GFLOP_BY_IMAGE_SIZE[S]
+    x = torch.from_numpy(rng.standard_normal((b, 4, S, S)).astype(np.float32))
     lab = torch.from_numpy((rng.standard_normal((b, 768)) * 0.5).astype(np.float32))
 
     def one_step():
@@ -145,8 +146,10 @@ def cpu_baseline(cfg, sd, budget_s=20.0):
         "sample": f"{what} of {b} images (forwards of batch {2 * b}) in {dt:.1f} s: pure-PyTorch fp32 restatement of the "
                   f"reference module graph on ATen CPU kernels, {best_n} threads ({phys} physical cores on the host)",
         "ms_per_denoise_step": per_step * 1e3,
-        "gflops": 2 * b * GFLOP_PER_SAMPLE_FWD / per_step,
+        "gflops": 2 * b * gflop_fwd / per_step,
     }
+    if S != 32:
+        return res                                                        # (the C restatement's second line: C1 only -- it is 6x slower still)
     try:
         set_num_threads(phys)
         ora = OracleDenoiser(cfg, sd)
@@ -365,8 +368,8 @@ def main():
             }
         if vae_info:
             line["with_vae"] = vae_info
-        if world == 1 and not args.no_cpu_baseline and S == 32:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, S=S)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1103,7 +1103,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             qf[ks] = *reinterpret_cast<const bf16x8*>(Qimg + row * 128 + (((ks * 2 + e_hi) ^ ((row >> 1) & 7)) << 4));
                     }
                     f32x16 o[2];
+#ifdef TLD_QA_DBG      // cost attribution build (wrong results): 1 = no attention arithmetic at all (K loop + images + stores only)
+                    float inv = 1.0f;
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[ct][r] = (float)qf[ct][r & 7];
+#else
                     const float inv = attn256_wave(Kimg, Vimg, qf, o, e_l31, e_hi);
+#endif
                     // whole 128-byte rows through a per-wave transpose patch (16 rows x 144 B), as attn1_kernel stores them; the patch overlays the
                     // wave's OWN query rows of the Q image (read by nobody else, and this wave's reads are long retired)
                     char* T = Qimg + wid * 4096;
