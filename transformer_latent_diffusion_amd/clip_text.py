@@ -9,7 +9,7 @@ where ``model`` is OpenAI CLIP "ViT-L/14" from ``clip.load`` (tld/diffusion.py:1
 package (openai/CLIP, unpinned in the reference; not in the reference checkout, not installed here).  This class is a
 drop-in for the ``model`` of that call: ``ClipTextEncoder(cfg).load_state_dict(clip_state_dict).to("cuda").encode_text(tokens)``
 returns ``[B, 768]`` on the tokens' device, so ``DiffusionTransformer(cfg, clip_model=ClipTextEncoder(...))`` keeps the
-labels on the GPU.  Tokenisation (BPE over CLIP's vocabulary file) stays with ``clip.tokenize``.
+labels on the GPU.  Tokenisation (BPE over CLIP's merges file) is clip_tokenizer.py's ``ClipTokenizer.tokenize`` or ``clip.tokenize``.
 
 Arithmetic runs in ``libtld_hip.so`` (``tld_clip_*``: bf16 MFMA projections, fp32 residual stream / LayerNorm / softmax);
 there is no CPU path.  A fresh object holds deterministic random weights (no checkpoint can be downloaded here).

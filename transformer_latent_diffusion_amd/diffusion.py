@@ -10,6 +10,7 @@ the exit edge.  CLIP and the VAE are third-party models outside the denoising pa
 from __future__ import annotations
 
 import numbers
+import os
 from dataclasses import asdict, dataclass
 from typing import Any, Optional
 
@@ -131,10 +132,13 @@ class DiffusionTransformer:
 
     ``vae`` / ``clip_model`` / ``text_encoder`` may be injected; otherwise ``diffusers`` and ``clip`` are
     imported lazily exactly where the reference uses them and a missing package raises ImportError.
+    ``tokenizer``: a ``ClipTokenizer`` (clip_tokenizer.py) or the path of CLIP's merges file -- prompts are then tokenised here
+    (``clip.tokenize(prompts, truncate=True)``, diffusion.py:136) and, with ``clip_model=ClipTextEncoder(...)``, the whole
+    text -> label edge runs without the ``clip`` package.
     """
 
     def __init__(self, cfg: LTDConfig, vae: Any = None, clip_model: Any = None, text_encoder=None,
-                 run_device: Optional[torch.device] = None):
+                 run_device: Optional[torch.device] = None, tokenizer: Any = None):
         dev = run_device if run_device is not None else device
         denoiser = Denoiser(**asdict(cfg.denoiser_cfg))
         denoiser = denoiser.to(cfg.denoiser_load.dtype)
@@ -148,6 +152,10 @@ class DiffusionTransformer:
             from diffusers import AutoencoderKL   # third-party exit edge
             vae = AutoencoderKL.from_pretrained(cfg.vae_cfg.vae_name, torch_dtype=cfg.vae_cfg.vae_dtype).to(dev)
         self._text_encoder = text_encoder
+        if isinstance(tokenizer, (str, os.PathLike)):
+            from .clip_tokenizer import ClipTokenizer
+            tokenizer = ClipTokenizer(bpe_path=tokenizer)
+        self._tokenizer = tokenizer
         if clip_model is None and text_encoder is None:
             import clip                            # third-party entry edge
             clip_model, _ = clip.load(cfg.clip_cfg.clip_model_name)
@@ -156,13 +164,17 @@ class DiffusionTransformer:
         self.device = dev
         self.diffuser = DiffusionGenerator(denoiser, vae, dev, cfg.denoiser_load.dtype)
 
+    def tokenize(self, prompts) -> Tensor:
+        if self._tokenizer is not None:
+            return self._tokenizer.tokenize(prompts, truncate=True)
+        import clip
+        return clip.tokenize(prompts, truncate=True)
+
     @torch.no_grad()
     def encode_text(self, prompts):
         if self._text_encoder is not None:
             return self._text_encoder(prompts).cpu()
-        import clip
-        tokens = clip.tokenize(prompts, truncate=True).to(self.device)
-        return self.clip_model.encode_text(tokens).cpu()
+        return self.clip_model.encode_text(self.tokenize(prompts).to(self.device)).cpu()
 
     @torch.no_grad()
     def generate_images_from_texts(self, prompts, class_guidance=6, seeds=11, n_iter=15):
@@ -182,8 +194,7 @@ class DiffusionTransformer:
         if self._text_encoder is not None:
             labels = self._text_encoder(prompts)
         else:
-            import clip
-            labels = self.clip_model.encode_text(clip.tokenize(prompts, truncate=True).to(self.device))
+            labels = self.clip_model.encode_text(self.tokenize(prompts).to(self.device))
         labels = labels.to(self.device, torch.float32)
         gen, size = self.diffuser, self.diffuser.model.image_size
         x_T = torch.cat([gen.initialize_image(None, 1, size, s) for s in seed_list])     # each request's own noise
