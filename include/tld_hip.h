@@ -269,10 +269,11 @@ TLD_API int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, co
  * ema may be NULL; grad_scale multiplies the gradient first (1 / world_size after a SUM all-reduce). */
 TLD_API int tld_train_adam_ema(tld_train* e, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, int64_t numel,
                                float lr, float beta1, float beta2, float eps, int32_t step, float ema_alpha, float grad_scale, void* hip_stream);
-/* Test hook: self-attention backward alone (256 tokens, head_dim 64): qk [M, 2d] bf16 (q | k), vt [B, H, 64, 256] bf16, o [M, d] bf16
- * (forward output), g [M, d] fp32 (dL/dO) -> dqkv [M, 3d] bf16 (dq | dk | dv).  Device pointers. */
-TLD_API int tld_debug_attention_bwd(const void* qk, const void* vt, const void* o, const float* g, void* dqkv, int32_t batch, int32_t heads,
-                                    void* hip_stream);
+/* Test hook: self-attention backward alone (head_dim 64; ntok = 64, 128 or a multiple of 256): qk [M, 2d] bf16 (q | k), vt [B, H, 64, ntok]
+ * bf16, o [M, d] bf16 (forward output), g [M, d] fp32 (dL/dO) -> dqkv [M, 3d] bf16 (dq | dk | dv).  scratch: 2 * batch * heads * ntok floats
+ * (row statistics between the two kernels of the ntok > 256 path; may be NULL otherwise).  Device pointers. */
+TLD_API int tld_debug_attention_bwd(const void* qk, const void* vt, const void* o, const float* g, void* dqkv, float* scratch, int32_t batch,
+                                    int32_t ntok, int32_t heads, void* hip_stream);
 /* Test / measurement hook: self-attention forward alone, softmax(q k^T / 8) v per head (head_dim 64; MHAttention.forward,
  * tld/transformer_blocks.py:31-48).  qk [batch * ntok, 2 d] bf16 (q | k), vt [batch, heads * 64, ntok] bf16 (V transposed per head),
  * att [batch * ntok, d] bf16 out, d = 64 heads.  iters launches back to back; *ms_per_launch (host pointer, may be NULL) receives the

@@ -14,18 +14,20 @@ from conftest import cfg_from_arr, load_golden, synth_weights
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _g15():
-    g = load_golden("g15_train_step.npz")
+def _g15(name="g15_train_step.npz"):
+    g = load_golden(name)
     cfg = cfg_from_arr(g["cfg"])
     sd = synth_weights(cfg, g["weight_seed"], g["weight_checksum"])
     return g, cfg, sd
 
 
-def test_oracle_autograd_pinned_against_reference_training_step():
+@pytest.mark.parametrize("name", ["g15_train_step.npz", "g17_train_step_1024tok.npz"])
+def test_oracle_autograd_pinned_against_reference_training_step(name):
     """oracle/torch_ref.train_step_reference (autograd over the restated graph) vs the reference's loss.backward(): loss, prediction and
-    the gradient of every parameter, <= 1e-4 relative L2 per tensor (measured 2e-6)."""
+    the gradient of every parameter, <= 1e-4 relative L2 per tensor (measured 2e-6).  g15: 256 tokens; g17: the 512 px fine-tuning
+    geometry (1024 tokens)."""
     from oracle.torch_ref import train_step_reference
-    g, cfg, sd = _g15()
+    g, cfg, sd = _g15(name)
     loss, pred, grads = train_step_reference(cfg, sd, torch.from_numpy(g["x"]), torch.from_numpy(g["noise_level"]), torch.from_numpy(g["noise"]),
                                              torch.from_numpy(g["y"]), torch.from_numpy(g["mask"]))
     assert abs(loss - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))

@@ -136,7 +136,7 @@ def lib() -> C.CDLL:
     L.tld_train_forward_backward.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp]
     L.tld_train_forward_backward_cb.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, GRAD_READY_FN, vp]
     L.tld_train_adam_ema.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, f32, f32, f32, f32, i32, f32, f32, vp]
-    L.tld_debug_attention_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
+    L.tld_debug_attention_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     L.tld_debug_dwconv_gelu.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, i32, i32, i32, vp]
     L.tld_debug_attention_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(C.c_float), vp]
     L.tld_train_destroy.argtypes = [vp]

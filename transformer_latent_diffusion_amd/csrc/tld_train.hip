@@ -25,7 +25,7 @@ using namespace tld;
 using namespace tld::train;
 
 namespace tld {
-int launch_attention_bwd(const bf16* qk, const bf16* vt, const bf16* o, const float* g, bf16* dqkv, int batch, int ntok, int heads, hipStream_t s);
+int launch_attention_bwd(const bf16* qk, const bf16* vt, const bf16* o, const float* g, bf16* dqkv, float* stats, int batch, int ntok, int heads, hipStream_t s);
 }
 
 namespace {
@@ -97,6 +97,7 @@ struct tld_train {
     float* gx;                           // dL/d(residual stream) fp32 [M, d]
     bf16 *gxb, *T1, *T2, *dbig, *dsmall, *dsmall2;
     float* scr;                          // small fp32 scratch ([pd, d])
+    float* attn_stats;                   // attention backward at > 256 tokens: [B, H, 2, N] (log-sum-exp | delta)
     float* splitk;                       // split-K partials of the weight-gradient GEMMs [8][max(hid, 3d)][d]
     float* part;                         // reduction partials
     size_t part_floats = 0;
@@ -146,7 +147,10 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
     if (cfg->embed_dim % 128 || cfg->embed_dim > 1024 || cfg->embed_dim <= 0) return tfail(TLD_ERR_INVALID, "embed_dim must be a multiple of 128, <= 1024");
     if (cfg->patch_size <= 0 || cfg->image_size % cfg->patch_size) return tfail(TLD_ERR_INVALID, "image_size must be a multiple of patch_size");
     const int G = cfg->image_size / cfg->patch_size;
-    if (G * G != 256) return tfail(TLD_ERR_INVALID, "the training step is built for 256-token latents (image_size / patch_size = 16); got %d tokens", G * G);
+    // token counts the attention kernels are built for (forward: launch_attention; backward: tld_train_attn.hip); the reference trains at
+    // 256 tokens and fine-tunes at 1024 / 4096 (README.md:23)
+    if (!(G * G == 64 || (G * G) % 256 == 0) || G > 64)
+        return tfail(TLD_ERR_INVALID, "the training step supports 64 tokens or a multiple of 256 up to 4096 (image_size / patch_size = 8, 16, 32, 64); got %d", G * G);
     if (cfg->n_channels * cfg->patch_size * cfg->patch_size > 64) return tfail(TLD_ERR_INVALID, "patch_dim must be <= 64");
     if (cfg->noise_embed_dims % 2 || cfg->max_batch <= 0 || cfg->n_layers <= 0) return tfail(TLD_ERR_INVALID, "bad configuration");
     DevGuard dg(cfg->device_id);
@@ -195,7 +199,7 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
         DALLOC(e->dout, M * pd); DALLOC(e->row_loss, M); DALLOC(e->io, 4);
         const size_t wide = hid > 3 * d ? hid : 3 * d;
         DALLOC(e->gx, M * d); DALLOC(e->gxb, M * d); e->tr_rows = M + 4096; DALLOC(e->T1, e->tr_rows * wide); DALLOC(e->T2, e->tr_rows * wide); DALLOC(e->dbig, M * hid);
-        DALLOC(e->dsmall, M * 3 * d); DALLOC(e->dsmall2, M * d); DALLOC(e->scr, (size_t)pd * d + 64);
+        DALLOC(e->dsmall, M * 3 * d); DALLOC(e->dsmall2, M * d); DALLOC(e->attn_stats, 2 * M * e->H); DALLOC(e->scr, (size_t)pd * d + 64);
         const size_t nchunk = (M + 255) / 256;
         size_t need = nchunk * 2 * (size_t)wide;                              // LN / colsum partials
         if (((M + 31) / 32) * 2 * (size_t)d > need) need = ((M + 31) / 32) * 2 * (size_t)d;   // LayerNorm-backward partials (32-row workgroups)
@@ -302,6 +306,13 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
     float* P = e->params; float* Gd = e->grads;
     const dim3 blk(256);
     const int nchunk = (M + 255) / 256;
+    const int dw_rows = dwconv_band_rows(G);
+    const dim3 dw_grid(B * (hid / 64) * ((G + dw_rows - 1) / dw_rows));
+    const size_t dw_lds = dwconv_lds_bytes(G);
+    {
+        static PerDeviceOnce once;
+        if (once.first()) hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     const float inv_numel = 1.0f / (float)((size_t)B * e->C * e->S * e->S);
     // the three small fp32 products on the tiled kernel (see tld_train_kernels.h)
     auto lin_fwd = [&](const float* in, int ldi, const float* W, const float* bias, float* out, int ldo, int R, int Nn, int K, float* pre, int gelu) {
@@ -351,7 +362,7 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
         hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x2, b.cr, b.x3, P + p.n3w, P + p.n3b, b.a3, b.st3, M, d);
         // x = x + MLPSepConv(LN3 x)   (:89-113,138)
         gemm_bf16(b.a3, d, b.wup, d, P + p.up_b, b.h, M, hid, d, s);
-        hipLaunchKernelGGL(dwconv_kernel, dim3(B * (hid / 64)), blk, (size_t)N * 128, s, b.h, b.dww_t, P + p.dw_b, b.hc, b.gl, B, G, hid, 0);
+        hipLaunchKernelGGL(dwconv_kernel, dw_grid, blk, dw_lds, s, b.h, b.dww_t, P + p.dw_b, b.hc, b.gl, B, G, hid, 0, dw_rows);
         gemm_bf16(b.gl, hid, b.wdown, hid, P + p.down_b, b.o, M, d, hid, s);
         bf16* xnext = i + 1 < e->L ? e->lb[i + 1].x1 : e->xfin;
         hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x3, b.o, xnext, (const float*)nullptr, (const float*)nullptr, (bf16*)nullptr, (float2*)nullptr, M, d);
@@ -459,7 +470,7 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
             hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((hid + 255) / 256, B * G), blk, 0, s, e->dbig, b.h, e->part, G, hid);
             hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 10 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B * G, hid);
         }
-        hipLaunchKernelGGL(dwconv_kernel, dim3(B * (hid / 64)), blk, (size_t)N * 128, s, e->dbig, b.dww_t, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1);   // dh -> b.gl (its forward value is consumed)
+        hipLaunchKernelGGL(dwconv_kernel, dw_grid, blk, dw_lds, s, e->dbig, b.dww_t, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1, dw_rows);   // dh -> b.gl (its forward value is consumed)
         colsum(b.gl, M, hid, Gd + p.up_b);
         weight_grad(b.gl, hid, b.a3, d, Gd + p.up_w);
         gemm_bf16(b.gl, hid, b.wup_t, hid, e->zero_bias, e->dsmall2, M, d, hid, s);                     // da3 = dh Wup
@@ -472,7 +483,7 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
         gemm_bf16(e->dsmall2, d, b.wq_t, d, e->zero_bias, e->dsmall, M, d, d, s);                       // da2 = dqc Wq
         ln_bwd_rows(e->dsmall, b.x2, b.st2, P + p.n2w, e->gx, 1, Gd + p.n2w, Gd + p.n2b, M, d);
         // ---- self-attention: att = SDPA(q, k, v);  qkv = a1 Wqkv^T;  a1 = LN1(x1)
-        if (launch_attention_bwd(b.qk, b.vt, b.att, e->gx, e->dsmall, B, N, H, s)) return tfail(TLD_ERR_INVALID, "attention backward supports 256 tokens");
+        if (launch_attention_bwd(b.qk, b.vt, b.att, e->gx, e->dsmall, e->attn_stats, B, N, H, s)) return tfail(TLD_ERR_INVALID, "attention backward: unsupported token count %d", N);
         weight_grad(e->dsmall, 3 * d, b.a1, d, Gd + p.qkv);
         gemm_bf16(e->dsmall, 3 * d, b.wqkv_t, 3 * d, e->zero_bias, e->dsmall2, M, d, 3 * d, s);         // da1 = dqkv Wqkv
         ln_bwd_rows(e->dsmall2, b.x1, b.st1, P + p.n1w, e->gx, 1, Gd + p.n1w, Gd + p.n1b, M, d);
@@ -526,14 +537,16 @@ int tld_train_adam_ema(tld_train* e, float* params, const float* grads, float* e
     return TLD_OK;
 }
 
-/* Test hook: backward of softmax(Q K^T / 8) V for `batch` samples x `heads` heads over 256 tokens.  qk [M, 2 d] bf16 (q | k), vt [B, H, 64, 256]
- * bf16, o [M, d] bf16 (the forward output), g [M, d] fp32 (dL/dO); dqkv [M, 3 d] bf16 out (dq | dk | dv).  Device pointers. */
-int tld_debug_attention_bwd(const void* qk, const void* vt, const void* o, const float* g, void* dqkv, int32_t batch, int32_t heads, void* hip_stream) {
-    if (!qk || !vt || !o || !g || !dqkv || batch <= 0 || heads <= 0) return tfail(TLD_ERR_INVALID, "bad argument");
+/* Test hook: backward of softmax(Q K^T / 8) V for `batch` samples x `heads` heads over `ntok` tokens (64, 128 or a multiple of 256).
+ * qk [M, 2 d] bf16 (q | k), vt [B, H, 64, ntok] bf16, o [M, d] bf16 (the forward output), g [M, d] fp32 (dL/dO); dqkv [M, 3 d] bf16 out
+ * (dq | dk | dv); scratch: 2 * batch * heads * ntok floats (used when ntok > 256).  Device pointers. */
+int tld_debug_attention_bwd(const void* qk, const void* vt, const void* o, const float* g, void* dqkv, float* scratch, int32_t batch, int32_t ntok,
+                            int32_t heads, void* hip_stream) {
+    if (!qk || !vt || !o || !g || !dqkv || batch <= 0 || heads <= 0 || ntok <= 0) return tfail(TLD_ERR_INVALID, "bad argument");
     PtrDeviceGuard guard(qk);
     if (launch_attention_bwd(reinterpret_cast<const bf16*>(qk), reinterpret_cast<const bf16*>(vt), reinterpret_cast<const bf16*>(o), g,
-                             reinterpret_cast<bf16*>(dqkv), batch, 256, heads, reinterpret_cast<hipStream_t>(hip_stream)))
-        return tfail(TLD_ERR_INVALID, "attention backward supports 256 tokens");
+                             reinterpret_cast<bf16*>(dqkv), scratch, batch, ntok, heads, reinterpret_cast<hipStream_t>(hip_stream)))
+        return tfail(TLD_ERR_INVALID, "attention backward: unsupported token count %d (or no scratch)", ntok);
     HIP_TRY(hipGetLastError());
     return TLD_OK;
 }

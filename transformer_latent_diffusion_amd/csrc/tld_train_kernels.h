@@ -604,17 +604,25 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict_
 // bf16 GEMM operands), so that a thread's 8 channels are two 16-byte loads per tap.
 // forward (flip = 0): out = b + sum_taps w[c][ky][kx] in[y + ky - 1][x + kx - 1];  also gelu_out = GELU(out) when given.
 // input gradient (flip = 1, no bias): din[y][x] = sum_taps w[c][ky][kx] dout[y - ky + 1][x - kx + 1]
-// One workgroup per (sample, 64-channel slab): the slab's 16 x 16 (G x G) tokens are staged in LDS (32 KB at G = 16) with 16-byte copies,
-// then a thread (channel quad, image row) slides a rotating 3 x 3 fp32 register window along the row (the inference path's
-// dwconv_gelu_kernel recipe): every input value is read from HBM once.
+// One workgroup per (sample, 64-channel slab, band of `R` image rows): the band's tokens plus one halo row on either side are staged in
+// LDS with 16-byte copies (the whole 16 x 16 image, 32 KB, at the training shape; 18 rows of 32 / 64 tokens at the fine-tuning
+// sizes), then a thread (channel quad, image row) slides a rotating 3 x 3 fp32 register window along the row (the inference path's
+// dwconv_gelu_kernel recipe): every input value is read from HBM once (halo rows twice).
+inline int dwconv_band_rows(int G) { return G < 16 ? G : 16; }
+inline size_t dwconv_lds_bytes(int G) { const int R = dwconv_band_rows(G); return (size_t)(R + 2 < G ? R + 2 : G) * G * 128; }
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias, bf16* __restrict__ out,
-                                                     bf16* __restrict__ gelu_out, int B, int G, int C, int flip) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];    // [G * G tokens][64 ch] bf16
-    const int nslab = C >> 6;
-    const int b = blockIdx.x / nslab, cc = blockIdx.x - b * nslab;
+                                                     bf16* __restrict__ gelu_out, int B, int G, int C, int flip, int R) {
+    extern __shared__ __attribute__((aligned(16))) char smem_[];   // [rows ylo .. yhi][G tokens][64 ch] bf16
+    const int nslab = C >> 6, nband = (G + R - 1) / R;
+    int bid = blockIdx.x;
+    const int band = bid % nband; bid /= nband;
+    const int b = bid / nslab, cc = bid - b * nslab;
     const int ntok = G * G;
+    const int y0 = band * R, y1 = y0 + R < G ? y0 + R : G;          // rows computed here
+    const int ylo = y0 > 0 ? y0 - 1 : 0, yhi = y1 < G ? y1 + 1 : G; // rows staged
+    char* smem = smem_ - (size_t)ylo * G * 128;                     // indexed with absolute token numbers below
     const bf16* src = in + (size_t)b * ntok * C + cc * 64;
-    for (int idx = threadIdx.x; idx < ntok * 8; idx += 256) {       // 8 x 16-B pieces per token
+    for (int idx = ylo * G * 8 + threadIdx.x; idx < yhi * G * 8; idx += 256) {       // 8 x 16-B pieces per token
         const int t = idx >> 3, q = idx & 7;
         *reinterpret_cast<uint4*>(smem + t * 128 + q * 16) = *reinterpret_cast<const uint4*>(src + (size_t)t * C + q * 8);
     }
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16* __restrict__ in
     float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias && !flip) bs = *reinterpret_cast<const float4*>(bias + c0);
     __syncthreads();
-    for (int i = threadIdx.x >> 4; i < G; i += 16) {
+    for (int i = y0 + (threadIdx.x >> 4); i < y1; i += 16) {
         const bool up_ok = i > 0, dn_ok = i + 1 < G;
         auto load_col = [&](int j, float4 (&col)[3]) {
             const bool jok = j >= 0 && j < G;
