@@ -274,6 +274,11 @@ TLD_API int tld_train_adam_ema(tld_train* e, float* params, const float* grads, 
  * (row statistics between the two kernels of the ntok > 256 path; may be NULL otherwise).  Device pointers. */
 TLD_API int tld_debug_attention_bwd(const void* qk, const void* vt, const void* o, const float* g, void* dqkv, float* scratch, int32_t batch,
                                     int32_t ntok, int32_t heads, void* hip_stream);
+/* Test hook: a weight gradient of the training step, dW[n_out, k_in] = dY^T X (dY [rows, n_out], X [rows, k_in] bf16 row-major; fp32 out):
+ * both operands are read as they are (the contraction index is the row), split-K partial sums go through `slices` (slice_floats fp32).
+ * n_out, k_in multiples of 256, rows a multiple of 64.  Device pointers. */
+TLD_API int tld_debug_wgrad(const void* dy, const void* x, float* dw, float* slices, int64_t slice_floats, int32_t rows, int32_t n_out, int32_t k_in,
+                            void* hip_stream);
 /* Test / measurement hook: self-attention forward alone, softmax(q k^T / 8) v per head (head_dim 64; MHAttention.forward,
  * tld/transformer_blocks.py:31-48).  qk [batch * ntok, 2 d] bf16 (q | k), vt [batch, heads * 64, ntok] bf16 (V transposed per head),
  * att [batch * ntok, d] bf16 out, d = 64 heads.  iters launches back to back; *ms_per_launch (host pointer, may be NULL) receives the

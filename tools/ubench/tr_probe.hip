@@ -38,6 +38,11 @@ __global__ __launch_bounds__(512) void time_kernel(long long* cycles, int* sink,
                 const char* p = smem + ((16 * (u & 3) + 8 * hi + (s >> 2)) * pitch) + (32 * ((u >> 2) & 7) + 16 * g1 + 4 * (s & 3)) * 2;
                 const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
                 acc += v[0] + v[3];
+            } else if (MODE == 3) {    // tr_seq on the GEMM's K-step image [64 k-rows][512 B], 64-byte blocks XOR-swizzled with (row & 3) | (row bit 3) << 2
+                const int row = 16 * (u & 3) + 8 * hi + (s >> 2), sw = (s >> 2) | (hi << 2);
+                const char* p = smem + row * 512 + (((((u >> 2) & 7)) ^ sw) << 6) + 32 * g1 + 8 * (s & 3);
+                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+                acc += v[0] + v[3];
             } else {                   // ds_read_b128 fragment: row 32 (u % 8) + l31, chunk 2 (u / 8 % 4) + hi
                 const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (32 * (u & 7) + (lane & 31)) * pitch + (2 * ((u >> 3) & 3) + hi) * 16);
                 acc += v[0] + v[3];
@@ -72,6 +77,7 @@ int main() {
     run(time_kernel<1>, 512, "tr_seq, dim-major [64][256]");
     run(time_kernel<1>, 528, "tr_seq, dim-major [64][256]");
     run(time_kernel<1>, 520, "tr_seq, dim-major [64][256]");
+    run(time_kernel<3>, 512, "tr_seq, [64][256], block-swizzled");
     run(time_kernel<2>, 144, "ds_read_b128 fragment");
     run(time_kernel<2>, 128, "ds_read_b128 fragment");
     return 0;

@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "tld_clip_create", "tld_clip_load_tensor", "tld_clip_finalize_weights", "tld_clip_encode_text", "tld_clip_read_buffer", "tld_clip_weight_bytes",
     "tld_clip_destroy",
     "tld_train_create", "tld_train_param_count", "tld_train_tensor_count", "tld_train_param_layout", "tld_train_set_angular_speeds", "tld_train_bind",
-    "tld_train_refresh_weights", "tld_train_forward_backward", "tld_train_forward_backward_cb", "tld_train_adam_ema", "tld_debug_attention_bwd", "tld_debug_attention_fwd", "tld_debug_dwconv_gelu", "tld_train_destroy",
+    "tld_train_refresh_weights", "tld_train_forward_backward", "tld_train_forward_backward_cb", "tld_train_adam_ema", "tld_debug_attention_bwd", "tld_debug_wgrad", "tld_debug_attention_fwd", "tld_debug_dwconv_gelu", "tld_train_destroy",
     "tld_last_error",
 )
 
@@ -137,6 +137,7 @@ def lib() -> C.CDLL:
     L.tld_train_forward_backward_cb.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, GRAD_READY_FN, vp]
     L.tld_train_adam_ema.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, f32, f32, f32, f32, i32, f32, f32, vp]
     L.tld_debug_attention_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.tld_debug_wgrad.argtypes = [vp, vp, vp, vp, C.c_int64, i32, i32, i32, vp]
     L.tld_debug_dwconv_gelu.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, i32, i32, i32, vp]
     L.tld_debug_attention_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, C.POINTER(C.c_float), vp]
     L.tld_train_destroy.argtypes = [vp]

@@ -346,11 +346,17 @@ struct GemmParams {
     float2* gn_partial;
     int gn_groups, gn_cpg, gn_hw;
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0
+    // Transposed-operand form (launch_gemm_tn; the weight gradients dW = dY^T X of the training step): A [k rows][lda] and W [k rows][ldw] are
+    // both row-major with the CONTRACTION index as the row, C[M, N] = sum_k A[k][m] W[k][n].  tn_ktotal = rows of both operands; K = rows per
+    // split (multiple of 64); w_batch_rows != 0: output rows [j w_batch_rows, (j + 1) w_batch_rows) are split j = operand rows [j K, min((j + 1) K,
+    // tn_ktotal)) against the same A columns (split-K into fp32 slices, summed by the caller in a fixed order).
+    int tn_ktotal;
     int half_tail;                // ring K loop: split the tiles of a partly filled last round by ROWS between two workgroups (set by the launcher)
     int dbg_epi;                  // experiment knob, builds with -DTLD_DBG_EPI only (TLD_EPI_DBG bit mask, see tld_gemm.hip)
 };
 
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s);
+void launch_gemm_tn(const GemmParams& p, hipStream_t s);        // EPI_F32, 256 x 256 tiles: M % 256 == 0, N % 256 == 0, K % 64 == 0, tn_ktotal % 64 == 0
 
 // thread-local message behind tld_last_error() (tld_engine.hip); for the other host translation units
 void set_last_error(const char* msg);

@@ -107,10 +107,16 @@ struct G256P : G256<BN> {
 // (scale layout [K/128][rows][4], see GemmParams).  Used for BASELINE config C4 (QKV / MLP GEMMs in fp8).
 // CONV = true: implicit 3x3 convolution over a channels-last image (GemmParams::conv): only the A-side DMA addressing
 // differs -- the per-lane row offsets are recomputed whenever the K loop moves to the next of the 9 taps.
-template <int BN, int EPI, bool F8 = false, bool CONV = false, bool RING = false>
+// TN = true (launch_gemm_tn): both operands are given with the contraction index as the ROW (GemmParams::tn_ktotal) -- the weight gradients
+// dW = dY^T X of the training step read dY and X as the forward / backward left them, no transposed copies.  A K-step's operand image is
+// then [64 k-rows][256 columns] (512-byte rows, two k-rows per 1-KiB DMA piece) and the MFMA fragments -- 8 consecutive k of one column
+// per lane -- come out of it with the transposing LDS read ds_read_b64_tr_b16 (two per fragment).  One wave-read touches 8 k-rows x 64
+// bytes at the same column offset, so the 64-byte blocks of a row are XOR-swizzled with (row & 3) | (row bit 3) << 2 on the DMA's source side.
+template <int BN, int EPI, bool F8 = false, bool CONV = false, bool RING = false, bool TN = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks) {
     using G = G256P<BN>;
     static_assert(!RING || (BN == 256 && !F8), "the half-tile ring exists for bf16 256 x 256 tiles");
+    static_assert(!TN || (BN == 256 && EPI == EPI_F32 && !F8 && !CONV && !RING), "transposed operands: fp32 output, 256 x 256 tiles, two-stage loop");
     using frag_t = std::conditional_t<F8, i32x8, bf16x8>;
     constexpr int ESZ = F8 ? 1 : 2;                                     // operand bytes per element
     constexpr int SC_OFF = G::LDS_BYTES;                                // F8: [stage][A scales 1 KiB | W scales 1 KiB] behind the stages
@@ -189,6 +195,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     unsigned voffA[G::A_PIECES], voffB[G::B_PIECES];
     // CONV: output pixel (y << 16 | x) of every A row this lane brings in, and the first pixel of its sample in the source image
     unsigned cpix[G::A_PIECES], cbase[G::A_PIECES];
+    size_t tnA = 0, tnW = 0;                                  // TN: byte offset of k-row 0 of the tile the DMA is working on (its split), per operand
     auto conv_tap = [&](int tap) {                            // A-row offsets of one of the nine taps (uniform tap)
         if constexpr (CONV) {
             const int ky = tap / 3;
@@ -214,6 +221,24 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         // loop as 64-bit loop invariants -- it then spilled them inside the K loop)
         int ln = lane;
         asm volatile("" : "+v"(ln));
+        if constexpr (TN) {
+            int split = 0, acol0 = tm0;
+            if (p.w_batch_rows) { split = tm0 / p.w_batch_rows; acol0 = tm0 - split * p.w_batch_rows; }
+            tnA = (size_t)split * p.K * p.lda * 2;
+            tnW = (size_t)split * p.K * p.ldw * 2;
+#pragma unroll
+            for (int q2 = 0; q2 < G::A_PIECES; ++q2) {
+                const int row = (wid * G::A_PIECES + q2) * 2 + (ln >> 5), c = ln & 31;
+                const int csrc = ((((c >> 2) ^ ((row & 3) | (((row >> 3) & 1) << 2))) << 2) | (c & 3));
+                unsigned v = __umul24((unsigned)row, (unsigned)(p.lda * 2)) + (unsigned)(acol0 * 2 + csrc * 16);
+                asm volatile("" : "+v"(v));
+                voffA[q2] = v;
+                unsigned w2 = __umul24((unsigned)row, (unsigned)(p.ldw * 2)) + (unsigned)(tn0 * 2 + csrc * 16);
+                asm volatile("" : "+v"(w2));
+                voffB[q2] = w2;
+            }
+            return;
+        }
         if constexpr (CONV) {
             const unsigned hw = (unsigned)(p.cv_h * p.cv_w);
             const unsigned shw = (unsigned)((p.cv_h >> p.cv_up) * (p.cv_w >> p.cv_up));
@@ -257,6 +282,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     };
     int conv_akb = 0;                                         // CONV: byte offset of the K-step's 64-channel block inside a pixel (A side)
     auto dma_piece = [&](int q2, int kbyte, char* st) {       // q2 < A_PIECES: A piece, else W piece; kbyte uniform
+        if constexpr (TN) {                                   // kbyte / 128 = K-step: 64 k-rows further down both operands
+            const bool isA = q2 < G::A_PIECES;
+            const char* base = isA ? reinterpret_cast<const char*>(p.A) + tnA + (size_t)(kbyte >> 7) * 64 * p.lda * 2
+                                   : reinterpret_cast<const char*>(p.W) + tnW + (size_t)(kbyte >> 7) * 64 * p.ldw * 2;
+            const unsigned vo = isA ? voffA[q2] : voffB[q2 - G::A_PIECES];
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + vo), (lptr_t)(st + (isA ? 0 : G::A_BYTES) + (wid * G::A_PIECES + (isA ? q2 : q2 - G::A_PIECES)) * 1024), 16, 0, 0);
+            return;
+        }
         if (q2 < G::A_PIECES) {
             const char* base = reinterpret_cast<const char*>(p.A) + (CONV ? conv_akb : kbyte);
             __builtin_amdgcn_global_load_lds((gptr_t)(base + voffA[q2]), (lptr_t)(st + (wid * G::A_PIECES + q2) * 1024), 16, 0, 0);
@@ -287,8 +320,31 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         dma_scales(m0, n0, 0, g & 1);
     };
     // ks: 16-element k-slice (bf16: 4 per K-step) / 64-element k-slice (fp8: 2 per K-step)
+    // TN: per-lane byte offsets of the (tile i / j, k-slice 0) fragment inside a stage: k-row 8 hi + (s >> 2), 64-byte block (column block ^ row swizzle)
+    unsigned tnoA[TN ? G::TM : 1], tnoB[TN ? G::TN : 1];
+    if constexpr (TN) {
+        const int s16 = lane & 15, g1 = (lane >> 4) & 1, rowl = 8 * hi + (s16 >> 2), sw = (s16 >> 2) | (hi << 2);
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i) tnoA[i] = (unsigned)(rowl * 512 + (((wm * G::TM + i) ^ sw) << 6) + 32 * g1 + 8 * (s16 & 3));
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) tnoB[j] = (unsigned)(G::A_BYTES + rowl * 512 + (((wn * G::TN + j) ^ sw) << 6) + 32 * g1 + 8 * (s16 & 3));
+    }
     auto load_frags = [&](const char* st, int ks, frag_t (&a)[G::TM], frag_t (&b)[G::TN]) {
-        if constexpr (!F8) {
+        if constexpr (TN) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            auto rd = [&](unsigned off) {
+                const char* q0 = st + off + ks * 8192;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q0));
+                const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q0 + 2048));
+                const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                return __builtin_bit_cast(bf16x8, v);
+            };
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i) a[i] = rd(tnoA[i]);
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j) b[j] = rd(tnoB[j]);
+        } else if constexpr (!F8) {
             const int kc = ks * 2 + hi;
 #pragma unroll
             for (int i = 0; i < G::TM; ++i) a[i] = read_frag(st, wm * G::WROWS + i * 32 + l31, kc);
@@ -438,6 +494,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         bool v_tile = false;
         if constexpr (IS_QKV) v_tile = n0 >= 2 * p.d;
 
+        int nkt = nk;                                 // K-steps of this tile
+        if constexpr (TN) {
+            const int split = p.w_batch_rows ? m0 / p.w_batch_rows : 0;
+            const int rows = p.tn_ktotal - split * p.K;
+            nkt = (rows < p.K ? rows : p.K) >> 6;
+        }
         const bool hmode = ht && it == ht_q;          // this item is one row half (ht_qa) of a left-over tile
         f32x16 acc[G::TM][G::TN];
 #pragma unroll
@@ -535,19 +597,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             wait_vmcnt<0>();                       // first K-step of the tile landed (own pieces) ...  (skipping this wait for tiles whose first K-step was waited for in the previous tile's last step -- it then only covers that tile's output stores -- measured neutral: kept)
             __builtin_amdgcn_s_barrier();          // ... everybody's; also: the previous epilogue's scratch reads are done
             if (grp) __builtin_amdgcn_s_barrier(); // stagger in
-            for (int k = 0; k < nk; ++k, ++g) {
-                if (k == (nk > 1 ? 1 : 0)) aux_dma();        // (K = 64: the tile's only K-step; every wave is past the previous epilogue since the barrier above)
+            for (int k = 0; k < nkt; ++k, ++g) {
+                if (k == (nkt > 1 ? 1 : 0)) aux_dma();        // (K = 64: the tile's only K-step; every wave is past the previous epilogue since the barrier above)
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
-                const bool more = (k + 1 < nk) || (has_next && EPI != EPI_UP_DWCONV2);
-                const int pkb = (k + 1 < nk) ? (k + 1) * G::BK * 2 : 0;
+                const bool more = (k + 1 < nkt) || (has_next && EPI != EPI_UP_DWCONV2);
+                const int pkb = (k + 1 < nkt) ? (k + 1) * G::BK * 2 : 0;
                 if constexpr (CONV) {
-                    if (k + 1 < nk) {
+                    if (k + 1 < nkt) {
                         if (++ccb == kpt) { ccb = 0; ++ctap; conv_tap(ctap); }
                     } else { ccb = 0; ctap = 0; }                   // (set_offsets below starts the next tile at tap 0)
                     conv_akb = ccb * (G::BK * 2);
                 }
-                if (k + 1 == nk && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
+                if (k + 1 == nkt && more) set_offsets(m0n, n0n);      // this step's DMA targets the next tile
                 // one k-slice per interval: 8 intervals (barriers) per bf16 K-step with 6 / 8 / 12 MFMAs each (two k-slices per interval -- 4
                 // barriers, two fragment sets -- measured slower); the tile DMA of the next K-step rides in the first two R intervals
                 // (one: -1.7 %, three: +-0.3 %); fragments are waited for AFTER the barrier (the latency overlaps the barrier wait) except in the
@@ -577,7 +639,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             dma_piece(q2, pkb, nst);
                         }
                         if (h == 0) {
-                            if (k + 1 < nk) dma_scales(m0, n0, k + 1, (g + 1) & 1);
+                            if (k + 1 < nkt) dma_scales(m0, n0, k + 1, (g + 1) & 1);
                             else dma_scales(m0n, n0n, 0, (g + 1) & 1);
                         }
                     }
@@ -1448,6 +1510,18 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
     else if (bn == 192) launch256p<192>(p, epilogue, s);
     else if (bn == 128) launch256p<128>(p, epilogue, s);
     else launch256p<256>(p, epilogue, s);
+}
+
+void launch_gemm_tn(const GemmParams& p, hipStream_t s) {
+    using G = G256P<256>;
+    const int ntiles = (p.M / 256) * (p.N / 256);
+    const int ncu = device_cu_count();
+    const int nblocks = ntiles < ncu ? ntiles : ncu;
+    static PerDeviceOnce once;
+    if (once.first())
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<256, EPI_F32, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            G::LDS_BYTES);
+    hipLaunchKernelGGL((gemm256p_kernel<256, EPI_F32, false, false, false, true>), dim3(nblocks), dim3(512), G::LDS_BYTES, s, p, nblocks);
 }
 
 }  // namespace tld

@@ -103,6 +103,7 @@ struct tld_train {
     size_t part_floats = 0;
     size_t tr_rows = 0, splitk_floats = 0;      // capacity of the transposed split-K operands (rows) and of the slice buffer
     bool weights_fresh = false;
+    bool tn_wgrad = true;                // weight gradients without transposed copies (TLD_TRAIN_TN_WGRAD=0: the transposing form, a test hook)
 };
 
 namespace {
@@ -124,6 +125,33 @@ int dalloc(tld_train* e, T** p, size_t n) {
 #define DALLOC(ptr, n) do { int _r = dalloc(e, &(ptr), (size_t)(n)); if (_r) return _r; } while (0)
 
 // C[Mr, Nc] = A[Mr, K] . W[Nc, K]^T on the engine's MFMA GEMM
+// dW[Nout, Kin] = dY^T X (dY [M, Nout], X [M, Kin], bf16 row-major) with both operands as they are -- the contraction index is the row, the MFMA
+// fragments come through the transposing LDS read (launch_gemm_tn): no transposed copies (8 transposes per block were 8.4 % of the step).
+// The output is small and the contraction long, so the rows are cut into `sk` runs of a multiple of 64 rows (split-K into fp32 slices
+// [sk][Nout][Kin], summed in a fixed order: bit-reproducible); sk = the count whose last round of 256 x 256 tiles is fullest.
+// Returns false (nothing launched) for shapes the kernel does not take.
+bool wgrad_tn(const bf16* dY, int Nout, const bf16* X, int Kin, int M, float* dW, float* slices, size_t slice_floats, hipStream_t s) {
+    if (Nout % 256 || Kin % 256 || M % 64 || M <= 0) return false;
+    const int ncu = device_cu_count();
+    const long per = (long)(Nout / 256) * (Kin / 256);
+    double best = 0.0; int bsk = 1, bms = M;
+    for (int c = 1; c <= 32; ++c) {
+        const int mp = ((M + c - 1) / c + 63) / 64 * 64;
+        if ((c > 1 && mp < 1024) || (long)(c - 1) * mp >= M) continue;                            // runs too short / last run empty
+        if (c > 1 && (size_t)c * Nout * Kin > slice_floats) continue;                            // slice workspace
+        const long tiles = per * c, rounds = (tiles + ncu - 1) / ncu;
+        const double eff = (double)tiles / (double)(rounds * ncu) * ((double)M / ((double)c * mp));
+        if (eff > best + 1e-9) { best = eff; bsk = c; bms = mp; }
+    }
+    GemmParams g{};
+    g.A = dY; g.lda = Nout; g.W = X; g.ldw = Kin; g.M = bsk * Nout; g.N = Kin; g.K = bms; g.tn_ktotal = M; g.ldc = Kin;
+    g.c_f32 = bsk == 1 ? dW : slices;
+    g.w_batch_rows = bsk == 1 ? 0 : Nout;
+    launch_gemm_tn(g, s);
+    if (bsk > 1) hipLaunchKernelGGL(sum_slices, dim3((unsigned)(((size_t)Nout * Kin / 4 + 255) / 256)), dim3(256), 0, s, slices, bsk, (size_t)Nout * Kin, dW, (size_t)Nout * Kin / 4);
+    return true;
+}
+
 void gemm_f32(const bf16* A, int lda, const bf16* W, int ldw, float* C, int Mr, int Nc, int K, hipStream_t s) {
     GemmParams g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = Mr; g.N = Nc; g.K = K; g.c_f32 = C; g.ldc = Nc;
@@ -159,6 +187,7 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
     e->d = cfg->embed_dim; e->L = cfg->n_layers; e->H = e->d / 64; e->G = G; e->N = G * G; e->S = cfg->image_size; e->C = cfg->n_channels;
     e->pd = e->C * cfg->patch_size * cfg->patch_size; e->hid = e->d * cfg->mlp_multiplier; e->ne = cfg->noise_embed_dims; e->text = cfg->text_emb_size;
     e->B = cfg->max_batch;
+    e->tn_wgrad = !(getenv("TLD_TRAIN_TN_WGRAD") && atoi(getenv("TLD_TRAIN_TN_WGRAD")) == 0);
     const int d = e->d, hid = e->hid, pd = e->pd;
     // canonical order: Denoiser.named_parameters() of the reference (tld/denoiser.py:85-114; pinned by tests/test_train_host.py)
     add_t(e, "fourier_feats.1.weight", (int64_t)d * e->ne, &e->ff1w); add_t(e, "fourier_feats.1.bias", d, &e->ff1b);
@@ -431,6 +460,7 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
             }
             if (bsk) { sk = bsk; ms = bms; }
         }
+        if (e->tn_wgrad && wgrad_tn(dY, Nout, X, Kin, M, dW, e->splitk, e->splitk_floats, s)) return;
         auto tr = [&](const bf16* src, int cols, bf16* dst) {
             if (M % 64 == 0 && cols % 64 == 0 && ms % 64 == 0)
                 hipLaunchKernelGGL(transpose_bf16_64, dim3(cols / 64, sk * ms / 64), blk, 0, s, src, cols, dst, ms, M, cols, sk);
@@ -547,6 +577,18 @@ int tld_debug_attention_bwd(const void* qk, const void* vt, const void* o, const
     if (launch_attention_bwd(reinterpret_cast<const bf16*>(qk), reinterpret_cast<const bf16*>(vt), reinterpret_cast<const bf16*>(o), g,
                              reinterpret_cast<bf16*>(dqkv), scratch, batch, ntok, heads, reinterpret_cast<hipStream_t>(hip_stream)))
         return tfail(TLD_ERR_INVALID, "attention backward: unsupported token count %d (or no scratch)", ntok);
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
+/* Test hook: the weight-gradient product dW[n_out, k_in] = dY^T X of the training step (dY [rows, n_out], X [rows, k_in] bf16 row-major, fp32 out)
+ * on the transposed-operand GEMM; `slices`: fp32 workspace of slice_floats elements for the split-K partial sums.  Device pointers. */
+int tld_debug_wgrad(const void* dy, const void* x, float* dw, float* slices, int64_t slice_floats, int32_t rows, int32_t n_out, int32_t k_in, void* hip_stream) {
+    if (!dy || !x || !dw || !slices || rows <= 0) return tfail(TLD_ERR_INVALID, "bad argument");
+    PtrDeviceGuard guard(dy);
+    if (!wgrad_tn(reinterpret_cast<const bf16*>(dy), n_out, reinterpret_cast<const bf16*>(x), k_in, rows, dw, slices, (size_t)slice_floats,
+                  reinterpret_cast<hipStream_t>(hip_stream)))
+        return tfail(TLD_ERR_SHAPE, "n_out and k_in must be multiples of 256, rows a multiple of 64");
     HIP_TRY(hipGetLastError());
     return TLD_OK;
 }
