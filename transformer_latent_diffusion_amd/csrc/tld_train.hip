@@ -85,7 +85,8 @@ struct tld_train {
     float* angular = nullptr;            // sinusoid buffer (not a parameter; tld/transformer_blocks.py:11-15)
     float* zero_bias = nullptr;
     // conditioning path
-    float *sinb, *h1, *g1v, *ycat, *y, *dy, *dycat, *dg1, *dkv;
+    float *sinb, *h1, *g1v, *ycat, *y, *dy, *dycat, *dg1;
+    float *kvc_all, *dkv_all, *dy_parts;     // per block, contiguous: (k | v) of the conditioning tokens [L][2B, 2d], its gradient, and each block's share of dL/dy [L][2B, d]
     float2* yst;
     // embedding
     float *p16, *p16n, *e, *patches, *de, *dpn, *dp16;
@@ -222,7 +223,8 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
     auto alloc_all = [&]() -> int {
         DALLOC(e->angular, e->ne / 2); DALLOC(e->zero_bias, 3 * hid > 4096 ? 3 * hid : 4096);
         DALLOC(e->sinb, B * e->ne); DALLOC(e->h1, B * d); DALLOC(e->g1v, B * d); DALLOC(e->ycat, B * 2 * d); DALLOC(e->y, B * 2 * d);
-        DALLOC(e->dy, B * 2 * d); DALLOC(e->dycat, B * 2 * d); DALLOC(e->dg1, B * d); DALLOC(e->dkv, B * 2 * 2 * d); DALLOC(e->yst, B * 2);
+        DALLOC(e->dy, B * 2 * d); DALLOC(e->dycat, B * 2 * d); DALLOC(e->dg1, B * d); DALLOC(e->dkv_all, (size_t)e->L * B * 2 * 2 * d); DALLOC(e->kvc_all, (size_t)e->L * B * 2 * 2 * d);
+        DALLOC(e->dy_parts, (size_t)e->L * B * 2 * d); DALLOC(e->yst, B * 2);
         DALLOC(e->p16, M * pd); DALLOC(e->p16n, M * pd); DALLOC(e->e, M * d); DALLOC(e->patches, M * pd); DALLOC(e->de, M * d);
         DALLOC(e->dpn, M * pd); DALLOC(e->dp16, M * pd); DALLOC(e->est1, M); DALLOC(e->est2, M); DALLOC(e->xfin, M * d);
         DALLOC(e->dout, M * pd); DALLOC(e->row_loss, M); DALLOC(e->io, 4);
@@ -247,7 +249,7 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
             DALLOC(q.x1, M * d); DALLOC(q.x2, M * d); DALLOC(q.x3, M * d); DALLOC(q.st1, M); DALLOC(q.st2, M); DALLOC(q.st3, M);
             DALLOC(q.a1, M * d); DALLOC(q.a2, M * d); DALLOC(q.a3, M * d); DALLOC(q.qk, M * 2 * d); DALLOC(q.vt, M * d); DALLOC(q.att, M * d);
             DALLOC(q.qc, M * d); DALLOC(q.cr, M * d); DALLOC(q.h, M * hid); DALLOC(q.hc, M * hid); DALLOC(q.gl, M * hid); DALLOC(q.o, M * d);
-            DALLOC(q.kvc, B * 2 * 2 * d); DALLOC(q.p0, M * e->H); DALLOC(q.dww_t, 9 * hid);
+            q.kvc = e->kvc_all + (size_t)i * B * 2 * 2 * d; DALLOC(q.p0, M * e->H); DALLOC(q.dww_t, 9 * hid);
         }
         return 0;
     };
@@ -371,8 +373,23 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
         q.x = x_noisy; q.conv_w = P + e->cvw; q.conv_b = P + e->cvb; q.ln1_w = P + e->l1w; q.ln1_b = P + e->l1b; q.lin_w = P + e->liw; q.lin_b = P + e->lib;
         q.ln2_w = P + e->l2w; q.ln2_b = P + e->l2b; q.pos = P + e->pos; q.p = e->p16; q.pn = e->p16n; q.st1 = e->est1; q.e = e->e; q.st2 = e->est2;
         q.x0 = e->lb[0].x1; q.B = B; q.C = e->C; q.S = e->S; q.patch = e->cfg.patch_size; q.grid = G; q.pd = pd; q.d = d;
-        hipLaunchKernelGGL(embed_fwd_kernel, dim3((M + 3) / 4), blk, 0, s, q);
+        const size_t lwb = (size_t)pd * d * 4;
+        if (lwb <= 65536) {
+            const int nwg = (M + 3) / 4 < 4 * device_cu_count() ? (M + 3) / 4 : 4 * device_cu_count();
+            if (d <= 256) hipLaunchKernelGGL((embed_fwd_lds_kernel<1>), dim3(nwg), blk, lwb, s, q);
+            else if (d <= 512) hipLaunchKernelGGL((embed_fwd_lds_kernel<2>), dim3(nwg), blk, lwb, s, q);
+            else if (d <= 768) hipLaunchKernelGGL((embed_fwd_lds_kernel<3>), dim3(nwg), blk, lwb, s, q);
+            else hipLaunchKernelGGL((embed_fwd_lds_kernel<4>), dim3(nwg), blk, lwb, s, q);
+        } else {
+            hipLaunchKernelGGL(embed_fwd_kernel, dim3((M + 3) / 4), blk, 0, s, q);
+        }
     }
+    // (k | v) of the two conditioning tokens for every block in one launch (tld/transformer_blocks.py:66-68): the blocks' parameters are laid out
+    // identically, so block i's kv_linear.weight sits i block-strides after block 0's
+    const long blk_stride = e->L > 1 ? (long)(e->lp[1].kv - e->lp[0].kv) : 0;
+    const long kv_stride = (long)e->B * 2 * 2 * d;
+    hipLaunchKernelGGL(tiled_f32_kernel, dim3((2 * d + 31) / 32, (2 * B + 31) / 32, e->L), dim3(256), 0, s, e->y, (long)d, 1L, P + e->lp[0].kv, (long)d, 1L,
+                       (const float*)nullptr, e->kvc_all, 2 * d, 2 * B, 2 * d, d, (float*)nullptr, 0, 0, 0L, blk_stride, kv_stride);
     for (int i = 0; i < e->L; ++i) {
         LayerB& b = e->lb[i]; const LayerP& p = e->lp[i];
         // x = x + SA(LN1 x)   (tld/transformer_blocks.py:51-59,136)
@@ -386,7 +403,6 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
         hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x1, b.att, b.x2, P + p.n2w, P + p.n2b, b.a2, b.st2, M, d);
         // x = x + CA(LN2 x, y)   (:62-72,137)
         gemm_bf16(b.a2, d, b.wq, d, e->zero_bias, b.qc, M, d, d, s);
-        lin_fwd(e->y, d, P + p.kv, nullptr, b.kvc, 2 * d, 2 * B, 2 * d, d, nullptr, 0);
         hipLaunchKernelGGL(cross_fwd_kernel, dim3(B * H), blk, 0, s, b.qc, b.kvc, b.cr, b.p0, N, d);
         hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x2, b.cr, b.x3, P + p.n3w, P + p.n3b, b.a3, b.st3, M, d);
         // x = x + MLPSepConv(LN3 x)   (:89-113,138)
@@ -405,14 +421,15 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
     auto reduce = [&](int nparts, size_t stride, size_t part_off, float* dst, int n, int acc) {
         hipLaunchKernelGGL(reduce_partials, dim3((n + 15) / 16), dim3(1024), 0, s, e->part + part_off, nparts, stride, dst, n, acc);
     };
-    auto ln_bwd_rows = [&](auto dyp, auto xp, const float2* st, const float* gamma, float* dx, int acc, float* dgamma, float* dbeta, int rows, int width) {
+    auto ln_bwd_rows = [&](auto dyp, auto xp, const float2* st, const float* gamma, float* dx, int acc, float* dgamma, float* dbeta, int rows, int width,
+                           bf16* dxb = nullptr) {
         using TDY = std::remove_cv_t<std::remove_pointer_t<decltype(dyp)>>;
         using TX = std::remove_cv_t<std::remove_pointer_t<decltype(xp)>>;
         const int nb = (rows + 31) / 32;                                  // 32 rows per workgroup: >= 1024 workgroups at the training batch
-        if (width == 768) hipLaunchKernelGGL((ln_bwd_q4_kernel<TDY, TX, 3>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows);
-        else if (width == 512) hipLaunchKernelGGL((ln_bwd_q4_kernel<TDY, TX, 2>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows);
-        else if (width == 256) hipLaunchKernelGGL((ln_bwd_q4_kernel<TDY, TX, 1>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows);
-        else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows, width);
+        if (width == 768) hipLaunchKernelGGL((ln_bwd_q4_kernel<TDY, TX, 3>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows, dxb);
+        else if (width == 512) hipLaunchKernelGGL((ln_bwd_q4_kernel<TDY, TX, 2>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows, dxb);
+        else if (width == 256) hipLaunchKernelGGL((ln_bwd_q4_kernel<TDY, TX, 1>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows, dxb);
+        else hipLaunchKernelGGL((ln_bwd_kernel<TDY, TX>), dim3(nb), blk, 0, s, dyp, xp, st, gamma, dx, acc, e->part, 32, rows, width, dxb);
         if (dbeta == dgamma + width) reduce(nb, 2 * (size_t)width, 0, dgamma, 2 * width, 0);       // (weight, bias) are neighbours in the flat vector: one launch
         else {
             reduce(nb, 2 * (size_t)width, 0, dgamma, width, 0);
@@ -479,16 +496,15 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
     };
 
     // out_proj: gx = dout Wout;  dWout = dout^T x_final;  dbout
-    hipLaunchKernelGGL(tail_dx_kernel, g1((size_t)M * d), blk, 0, s, e->dout, P + e->outw, e->gx, M, pd, d);
+    hipLaunchKernelGGL(tail_dx_kernel, g1((size_t)M * d), blk, 0, s, e->dout, P + e->outw, e->gx, e->gxb, M, pd, d);      // gx and its bf16 copy (the top block's GEMM operand)
     hipLaunchKernelGGL((tall_dw_partial<bf16>), dim3((pd * d + 255) / 256, nchunk), blk, 0, s, e->dout, pd, e->xfin, d, M, 256, e->part);
     reduce(nchunk, (size_t)pd * d, 0, Gd + e->outw, pd * d, 0);
     colsum(e->dout, M, pd, Gd + e->outb);
-    HIP_TRY(hipMemsetAsync(e->dy, 0, (size_t)B * 2 * d * 4, s));
 
     for (int i = e->L - 1; i >= 0; --i) {
         LayerB& b = e->lb[i]; const LayerP& p = e->lp[i];
         // ---- MLP: o = g Wdown^T + b;  g = GELU(hc);  hc = dwconv(h);  h = a3 Wup^T + b;  a3 = LN3(x3)
-        hipLaunchKernelGGL(cast_f32_bf16, g1((size_t)M * d), blk, 0, s, e->gx, e->gxb, (size_t)M * d);
+        // (e->gxb = bf16(e->gx): written by whoever completed gx -- tail_dx_kernel for the top block, the LayerNorm-1 backward of the block above otherwise)
         colsum(e->gxb, M, d, Gd + p.down_b);
         weight_grad(e->gxb, d, b.gl, hid, Gd + p.down_w);
         gemm_bf16(e->gxb, d, b.wdown_t, d, e->zero_bias, e->dbig, M, hid, d, s);                         // dg = go Wdown
@@ -506,9 +522,9 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
         gemm_bf16(b.gl, hid, b.wup_t, hid, e->zero_bias, e->dsmall2, M, d, hid, s);                     // da3 = dh Wup
         ln_bwd_rows(e->dsmall2, b.x3, b.st3, P + p.n3w, e->gx, 1, Gd + p.n3w, Gd + p.n3b, M, d);
         // ---- cross-attention: cr = CA(qc, kv);  qc = a2 Wq^T;  kv = y Wkv^T;  a2 = LN2(x2)
-        hipLaunchKernelGGL(cross_bwd_kernel, dim3(B * H), blk, (size_t)2 * N * 4, s, e->gx, b.qc, b.kvc, b.p0, e->dsmall2, e->dkv, N, d);   // dqc -> dsmall2
-        lin_dw(e->dkv, 2 * d, e->y, d, Gd + p.kv, nullptr, 2 * B, 2 * d, d);
-        lin_dx(e->dkv, 2 * d, P + p.kv, e->dy, d, 2 * B, 2 * d, d, 1);
+        float* dkv = e->dkv_all + (size_t)i * kv_stride;
+        hipLaunchKernelGGL(cross_bwd_kernel, dim3(B * H), blk, (size_t)2 * N * 4, s, e->gx, b.qc, b.kvc, b.p0, e->dsmall2, dkv, N, d);   // dqc -> dsmall2
+        lin_dw(dkv, 2 * d, e->y, d, Gd + p.kv, nullptr, 2 * B, 2 * d, d);       // (per block: its gradient range must be complete at the grad_ready call below)
         weight_grad(e->dsmall2, d, b.a2, d, Gd + p.q);
         gemm_bf16(e->dsmall2, d, b.wq_t, d, e->zero_bias, e->dsmall, M, d, d, s);                       // da2 = dqc Wq
         ln_bwd_rows(e->dsmall, b.x2, b.st2, P + p.n2w, e->gx, 1, Gd + p.n2w, Gd + p.n2b, M, d);
@@ -516,11 +532,15 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
         if (launch_attention_bwd(b.qk, b.vt, b.att, e->gx, e->dsmall, e->attn_stats, B, N, H, s)) return tfail(TLD_ERR_INVALID, "attention backward: unsupported token count %d", N);
         weight_grad(e->dsmall, 3 * d, b.a1, d, Gd + p.qkv);
         gemm_bf16(e->dsmall, 3 * d, b.wqkv_t, 3 * d, e->zero_bias, e->dsmall2, M, d, 3 * d, s);         // da1 = dqkv Wqkv
-        ln_bwd_rows(e->dsmall2, b.x1, b.st1, P + p.n1w, e->gx, 1, Gd + p.n1w, Gd + p.n1b, M, d);
+        ln_bwd_rows(e->dsmall2, b.x1, b.st1, P + p.n1w, e->gx, 1, Gd + p.n1w, Gd + p.n1b, M, d, i > 0 ? e->gxb : nullptr);
         // every gradient of this block is enqueued (its 15 tensors are one contiguous range of the flat vector): the data-parallel
         // reduction of that slice can start now, under the backward of the blocks below
         if (grad_ready) grad_ready(user, p.qkv, (p.n3b + d) - p.qkv);
     }
+    // dL/dy = sum over blocks of dkv_i Wkv_i: one batched launch into per-block parts, then a fixed-order sum
+    hipLaunchKernelGGL(tiled_f32_kernel, dim3((d + 31) / 32, (2 * B + 31) / 32, e->L), dim3(256), 0, s, e->dkv_all, (long)(2 * d), 1L, P + e->lp[0].kv, 1L, (long)d,
+                       (const float*)nullptr, e->dy_parts, d, 2 * B, d, 2 * d, (float*)nullptr, 0, 0, kv_stride, blk_stride, (long)e->B * 2 * d);
+    hipLaunchKernelGGL(reduce_partials, dim3((2 * B * d + 15) / 16), dim3(1024), 0, s, e->dy_parts, e->L, (size_t)e->B * 2 * d, e->dy, 2 * B * d, 0);
     // ---- patch embedding: x0 = LN2(e) + pos;  e = pn Wlin^T + b;  pn = LN1(p);  p = conv(x)     (tld/denoiser.py:34-45,75-77)
     hipLaunchKernelGGL(pos_grad_kernel, g1((size_t)N * d), blk, 0, s, e->gx, Gd + e->pos, B, N, d);
     ln_bwd_rows(e->gx, e->e, e->est2, P + e->l2w, e->de, 0, Gd + e->l2w, Gd + e->l2b, M, d);

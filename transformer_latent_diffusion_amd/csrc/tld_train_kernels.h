@@ -36,7 +36,10 @@ __device__ __forceinline__ float gelu_grad(float x) {
 // 32 x 32 output tile per 256-thread workgroup (2 x 2 per thread), 32-deep K-steps through LDS; exact fp32 FMA chains in k order.
 __global__ __launch_bounds__(256) void tiled_f32_kernel(const float* __restrict__ A, long sai, long sak, const float* __restrict__ B, long sbj, long sbk,
                                                         const float* __restrict__ bias, float* __restrict__ C, int ldc, int I, int J, int K,
-                                                        float* __restrict__ pre, int gelu, int accumulate) {
+                                                        float* __restrict__ pre, int gelu, int accumulate, long za = 0, long zb = 0, long zc = 0) {
+    // blockIdx.z: a batch of equally shaped products (the 12 blocks' kv projections of the conditioning tokens in one launch: each is 0.6 GFLOP and
+    // latency-bound on its own, 36 us per launch), operand / output z at element offsets z za, z zb, z zc
+    A += (long)blockIdx.z * za; B += (long)blockIdx.z * zb; C += (long)blockIdx.z * zc;
     __shared__ float sa[32][33], sb[32][33];
     const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
 template <typename TDY, typename TX>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float2* __restrict__ stats,
                                                      const float* __restrict__ gamma, float* __restrict__ dx, int accumulate,
-                                                     float* __restrict__ part, int rows_per_block, int M, int d) {
+                                                     float* __restrict__ part, int rows_per_block, int M, int d, bf16* __restrict__ dx_bf16 = nullptr) {
     __shared__ float red[4][2][1024];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int J = d >> 6;
@@ -169,7 +172,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
         for (int j = 0; j < kMaxJ; ++j) if (j < J) {
             const float o = st.y * (g[j] - m1 - xh[j] * m2);
             float* px = dx + (size_t)row * d + lane + 64 * j;
-            *px = accumulate ? *px + o : o;
+            const float v = accumulate ? *px + o : o;
+            *px = v;
+            if (dx_bf16) dx_bf16[(size_t)row * d + lane + 64 * j] = (bf16)v;      // the next block's GEMM operand (was a separate cast pass)
         }
     }
 #pragma unroll
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const TDY* __restrict__ dy,
 template <typename TDY, typename TX, int NQ>
 __global__ __launch_bounds__(256) void ln_bwd_q4_kernel(const TDY* __restrict__ dy, const TX* __restrict__ x, const float2* __restrict__ stats,
                                                         const float* __restrict__ gamma, float* __restrict__ dx, int accumulate,
-                                                        float* __restrict__ part, int rows_per_block, int M) {
+                                                        float* __restrict__ part, int rows_per_block, int M, bf16* __restrict__ dx_bf16 = nullptr) {
     constexpr int d = NQ * 256;
     __shared__ float red[4][2][d];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -215,6 +220,11 @@ __global__ __launch_bounds__(256) void ln_bwd_q4_kernel(const TDY* __restrict__ 
             f32x4* px = reinterpret_cast<f32x4*>(dx + (size_t)row * d + j * 256 + 4 * lane);
             if (accumulate) o += *px;
             *px = o;
+            if (dx_bf16) {
+                bf16x4 ob;
+                ob[0] = (bf16)o[0]; ob[1] = (bf16)o[1]; ob[2] = (bf16)o[2]; ob[3] = (bf16)o[3];
+                *reinterpret_cast<bf16x4*>(dx_bf16 + (size_t)row * d + j * 256 + 4 * lane) = ob;
+            }
         }
     }
 #pragma unroll
@@ -484,6 +494,89 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(EmbedTrain q) {
     for (int j = 0; j < kMaxJ; ++j) if (j < J) {
         const int c = lane + 64 * j;
         q.x0[(size_t)row * q.d + c] = (bf16)((ev[j] - m2) * r2 * q.ln2_w[c] + q.ln2_b[c] + q.pos[(size_t)t * q.d + c]);
+    }
+}
+// The same with the Linear's weight staged transposed in LDS ([pd][d] fp32, <= 64 KB) and a lane owning 4 CONSECUTIVE features per 256-feature
+// block: 16-byte LDS reads / global stores instead of 64-byte-strided weight loads per token (763 -> ~60 us at the training shape).  Waves walk the
+// token rows with a grid stride.  Same arithmetic order per output as embed_fwd_kernel (bias first, features f ascending).
+template <int JB>      // 256-feature blocks: d <= 256 JB
+__global__ __launch_bounds__(256) void embed_fwd_lds_kernel(EmbedTrain q) {
+    extern __shared__ __attribute__((aligned(16))) float lw[];     // [pd][d]
+    const int N = q.grid * q.grid, M = q.B * N, d = q.d, pd = q.pd;
+    for (int i = threadIdx.x; i < pd * d; i += 256) { const int c = i / pd, f = i - c * pd; lw[f * d + c] = q.lin_w[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pp = q.patch * q.patch, taps = q.C * pp;
+    float4 lb[JB], g2[JB], b2[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+        const int c0 = 4 * lane + 256 * j;
+        if (c0 < d) { lb[j] = *reinterpret_cast<const float4*>(q.lin_b + c0); g2[j] = *reinterpret_cast<const float4*>(q.ln2_w + c0); b2[j] = *reinterpret_cast<const float4*>(q.ln2_b + c0); }
+        else lb[j] = g2[j] = b2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float cb = lane < pd ? q.conv_b[lane] : 0.f, l1w = lane < pd ? q.ln1_w[lane] : 0.f, l1b = lane < pd ? q.ln1_b[lane] : 0.f;
+    for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+        const int b = row / N, t = row - b * N, gy = t / q.grid, gx = t - gy * q.grid;
+        float pv = 0.f;
+        if (lane < pd) {
+            pv = cb;
+            for (int k = 0; k < taps; ++k) {
+                const int c = k / pp, r = k - c * pp, p1 = r / q.patch, p2 = r - p1 * q.patch;
+                pv = fmaf(q.conv_w[lane * taps + k], q.x[(((size_t)b * q.C + c) * q.S + gy * q.patch + p1) * q.S + gx * q.patch + p2], pv);
+            }
+            q.p[(size_t)row * pd + lane] = pv;
+        }
+        const float m1 = wave_sum(lane < pd ? pv : 0.f) / (float)pd;
+        const float c1 = lane < pd ? pv - m1 : 0.f;
+        const float r1 = rsqrtf(wave_sum(c1 * c1) / (float)pd + kEps);
+        const float pn = lane < pd ? c1 * r1 * l1w + l1b : 0.f;
+        if (lane < pd) q.pn[(size_t)row * pd + lane] = pn;
+        if (lane == 0) q.st1[row] = make_float2(m1, r1);
+        float4 ev[JB];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) ev[j] = lb[j];
+        for (int f = 0; f < pd; ++f) {
+            const float pf = __shfl(pn, f, 64);
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                const int c0 = 4 * lane + 256 * j;
+                if (c0 < d) {
+                    const float4 w = *reinterpret_cast<const float4*>(lw + f * d + c0);
+                    ev[j].x = fmaf(pf, w.x, ev[j].x); ev[j].y = fmaf(pf, w.y, ev[j].y); ev[j].z = fmaf(pf, w.z, ev[j].z); ev[j].w = fmaf(pf, w.w, ev[j].w);
+                }
+            }
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int c0 = 4 * lane + 256 * j;
+            if (c0 < d) { *reinterpret_cast<float4*>(q.e + (size_t)row * d + c0) = ev[j]; sm += (ev[j].x + ev[j].y) + (ev[j].z + ev[j].w); }
+        }
+        const float m2 = wave_sum(sm) / (float)d;
+        float v2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int c0 = 4 * lane + 256 * j;
+            if (c0 < d) {
+                const float a = ev[j].x - m2, bq = ev[j].y - m2, c = ev[j].z - m2, dd = ev[j].w - m2;
+                v2 = fmaf(a, a, v2); v2 = fmaf(bq, bq, v2); v2 = fmaf(c, c, v2); v2 = fmaf(dd, dd, v2);
+            }
+        }
+        const float r2 = rsqrtf(wave_sum(v2) / (float)d + kEps);
+        if (lane == 0) q.st2[row] = make_float2(m2, r2);
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int c0 = 4 * lane + 256 * j;
+            if (c0 < d) {
+                const float4 ps = *reinterpret_cast<const float4*>(q.pos + (size_t)t * d + c0);
+                bf16x4 o;
+                o[0] = (bf16)((ev[j].x - m2) * r2 * g2[j].x + b2[j].x + ps.x);
+                o[1] = (bf16)((ev[j].y - m2) * r2 * g2[j].y + b2[j].y + ps.y);
+                o[2] = (bf16)((ev[j].z - m2) * r2 * g2[j].z + b2[j].z + ps.z);
+                o[3] = (bf16)((ev[j].w - m2) * r2 * g2[j].w + b2[j].w + ps.w);
+                *reinterpret_cast<bf16x4*>(q.x0 + (size_t)row * d + c0) = o;
+            }
+        }
     }
 }
 // dpos[t, c] = sum_b g[b N + t, c]
@@ -862,7 +955,7 @@ __global__ void loss_reduce_kernel(const float* __restrict__ row_loss, int M, fl
     if (threadIdx.x == 0) *loss = red[0] * inv_numel;
 }
 // backward into the stream: gx[row, c] = sum_f dout[row, f] W[f, c]   (fp32, written)
-__global__ void tail_dx_kernel(const float* __restrict__ dout, const float* __restrict__ W, float* __restrict__ gx, int M, int pd, int d) {
+__global__ void tail_dx_kernel(const float* __restrict__ dout, const float* __restrict__ W, float* __restrict__ gx, bf16* __restrict__ gx_bf16, int M, int pd, int d) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)M * d) return;
     const int c = (int)(i % d);
@@ -870,6 +963,7 @@ __global__ void tail_dx_kernel(const float* __restrict__ dout, const float* __re
     float a = 0.f;
     for (int f = 0; f < pd; ++f) a = fmaf(dout[row * pd + f], W[(size_t)f * d + c], a);
     gx[i] = a;
+    gx_bf16[i] = (bf16)a;
 }
 // generic "tall" weight gradient with a SMALL output (out-projection, patch Linear, patch conv):
 // part[chunk][n][k] = sum_{rows of chunk} dy[r, n] x[r, k];  n < Nn <= 64, thread per (n, k);  dy fp32, x bf16 or fp32
