@@ -384,6 +384,16 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
             hipLaunchKernelGGL(embed_fwd_kernel, dim3((M + 3) / 4), blk, 0, s, q);
         }
     }
+    // x_out = x_in + delta [; a_out = LN(x_out), stats]   (delta == nullptr: LayerNorm of x_in alone)
+    auto resid_ln = [&](const bf16* x_in, const bf16* delta, bf16* x_out, const float* gamma, const float* beta, bf16* a_out, float2* st) {
+        const dim3 grid((M + 3) / 4);
+        if (d == 768) hipLaunchKernelGGL((resid_add_ln_q4_kernel<3>), grid, blk, 0, s, x_in, delta, x_out, gamma, beta, a_out, st, M);
+        else if (d == 512) hipLaunchKernelGGL((resid_add_ln_q4_kernel<2>), grid, blk, 0, s, x_in, delta, x_out, gamma, beta, a_out, st, M);
+        else if (d == 256) hipLaunchKernelGGL((resid_add_ln_q4_kernel<1>), grid, blk, 0, s, x_in, delta, x_out, gamma, beta, a_out, st, M);
+        else if (d == 1024) hipLaunchKernelGGL((resid_add_ln_q4_kernel<4>), grid, blk, 0, s, x_in, delta, x_out, gamma, beta, a_out, st, M);
+        else if (delta) hipLaunchKernelGGL(resid_add_ln_kernel, grid, blk, 0, s, x_in, delta, x_out, gamma, beta, a_out, st, M, d);
+        else hipLaunchKernelGGL((ln_fwd_kernel<bf16>), grid, blk, 0, s, x_in, gamma, beta, a_out, (float*)nullptr, st, (const float*)nullptr, 1, M, d);
+    };
     // (k | v) of the two conditioning tokens for every block in one launch (tld/transformer_blocks.py:66-68): the blocks' parameters are laid out
     // identically, so block i's kv_linear.weight sits i block-strides after block 0's
     const long blk_stride = e->L > 1 ? (long)(e->lp[1].kv - e->lp[0].kv) : 0;
@@ -393,24 +403,25 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
     for (int i = 0; i < e->L; ++i) {
         LayerB& b = e->lb[i]; const LayerP& p = e->lp[i];
         // x = x + SA(LN1 x)   (tld/transformer_blocks.py:51-59,136)
-        hipLaunchKernelGGL((ln_fwd_kernel<bf16>), dim3((M + 3) / 4), blk, 0, s, b.x1, P + p.n1w, P + p.n1b, b.a1, (float*)nullptr, b.st1, (const float*)nullptr, 1, M, d);
+        if (i == 0) resid_ln(b.x1, (const bf16*)nullptr, (bf16*)nullptr, P + p.n1w, P + p.n1b, b.a1, b.st1);      // (blocks > 0: LN1 rides on the previous block's last residual add)
         {
             GemmParams g{};
             g.A = b.a1; g.lda = d; g.W = b.wqkv; g.ldw = d; g.M = M; g.N = 3 * d; g.K = d; g.out_bf16 = b.qk; g.ldo = 2 * d; g.vt = b.vt; g.ntok = N; g.d = d;
             launch_gemm(g, EPI_QKV, s);
         }
         launch_attention(b.qk, b.vt, b.att, B, N, H, s);
-        hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x1, b.att, b.x2, P + p.n2w, P + p.n2b, b.a2, b.st2, M, d);
+        resid_ln(b.x1, b.att, b.x2, P + p.n2w, P + p.n2b, b.a2, b.st2);
         // x = x + CA(LN2 x, y)   (:62-72,137)
         gemm_bf16(b.a2, d, b.wq, d, e->zero_bias, b.qc, M, d, d, s);
         hipLaunchKernelGGL(cross_fwd_kernel, dim3(B * H), blk, 0, s, b.qc, b.kvc, b.cr, b.p0, N, d);
-        hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x2, b.cr, b.x3, P + p.n3w, P + p.n3b, b.a3, b.st3, M, d);
+        resid_ln(b.x2, b.cr, b.x3, P + p.n3w, P + p.n3b, b.a3, b.st3);
         // x = x + MLPSepConv(LN3 x)   (:89-113,138)
         gemm_bf16(b.a3, d, b.wup, d, P + p.up_b, b.h, M, hid, d, s);
         hipLaunchKernelGGL(dwconv_kernel, dw_grid, blk, dw_lds, s, b.h, b.dww_t, P + p.dw_b, b.hc, b.gl, B, G, hid, 0, dw_rows);
         gemm_bf16(b.gl, hid, b.wdown, hid, P + p.down_b, b.o, M, d, hid, s);
         bf16* xnext = i + 1 < e->L ? e->lb[i + 1].x1 : e->xfin;
-        hipLaunchKernelGGL(resid_add_ln_kernel, dim3((M + 3) / 4), blk, 0, s, b.x3, b.o, xnext, (const float*)nullptr, (const float*)nullptr, (bf16*)nullptr, (float2*)nullptr, M, d);
+        if (i + 1 < e->L) resid_ln(b.x3, b.o, xnext, P + e->lp[i + 1].n1w, P + e->lp[i + 1].n1b, e->lb[i + 1].a1, e->lb[i + 1].st1);      // + the next block's LN1
+        else resid_ln(b.x3, b.o, xnext, (const float*)nullptr, (const float*)nullptr, (bf16*)nullptr, (float2*)nullptr);
     }
     // out_proj + unpatchify + MSE (tld/denoiser.py:47-52,72,82; tld/train.py:167)
     hipLaunchKernelGGL(tail_fwd_kernel, dim3((M + 3) / 4), blk, 0, s, e->xfin, P + e->outw, P + e->outb, target, pred_out, e->dout, e->row_loss, B, e->C, e->S,

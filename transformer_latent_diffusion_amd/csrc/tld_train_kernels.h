@@ -139,6 +139,48 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const TX* __restrict__ x, c
         if (out_f) out_f[(size_t)row * d + c] = o;
     }
 }
+// d = 256 NQ forms of the two row kernels of a block's forward (lane l owns features {4 l .. 4 l + 3} + 256 j: 8-byte accesses; the 2-byte
+// forms ran at 3.6 TB/s): x_out = x_in + delta (bf16-rounded, as the reference's bf16 residual stream would be) and, when a_out is given,
+// a_out = LN(x_out) with its (mean, rstd);  delta == nullptr: plain LayerNorm of x_in (x_out is not written).
+template <int NQ>
+__global__ __launch_bounds__(256) void resid_add_ln_q4_kernel(const bf16* __restrict__ x_in, const bf16* __restrict__ delta, bf16* __restrict__ x_out,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ a_out,
+                                                              float2* __restrict__ stats, int M) {
+    constexpr int d = NQ * 256;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    f32x4 v[NQ];
+    f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const size_t o = (size_t)row * d + j * 256 + 4 * lane;
+        if (delta) {
+            const f32x4 t = ldf4(x_in + o) + ldf4(delta + o);
+            bf16x4 r;
+            r[0] = (bf16)t[0]; r[1] = (bf16)t[1]; r[2] = (bf16)t[2]; r[3] = (bf16)t[3];
+            *reinterpret_cast<bf16x4*>(x_out + o) = r;
+            v[j] = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        } else {
+            v[j] = ldf4(x_in + o);
+        }
+        s4 += v[j];
+    }
+    if (!a_out) return;
+    const float mean = wave_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) / (float)d;
+    f32x4 q4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) { const f32x4 c = v[j] - mean; q4 = __builtin_elementwise_fma(c, c, q4); }
+    const float rstd = rsqrtf(wave_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) / (float)d + kEps);
+    if (lane == 0) stats[row] = make_float2(mean, rstd);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int c = j * 256 + 4 * lane;
+        const f32x4 o = (v[j] - mean) * rstd * ldf4(gamma + c) + ldf4(beta + c);
+        bf16x4 r;
+        r[0] = (bf16)o[0]; r[1] = (bf16)o[1]; r[2] = (bf16)o[2]; r[3] = (bf16)o[3];
+        *reinterpret_cast<bf16x4*>(a_out + (size_t)row * d + c) = r;
+    }
+}
 // backward: dx = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;  written (accumulate = 0) or added (1) into dx (fp32);
 // per-workgroup partial sums of dgamma = sum dy xhat and dbeta = sum dy over the workgroup's rows -> part[blockIdx][2][d]
 template <typename TDY, typename TX>
