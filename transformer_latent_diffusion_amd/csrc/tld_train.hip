@@ -519,15 +519,15 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
         colsum(e->gxb, M, d, Gd + p.down_b);
         weight_grad(e->gxb, d, b.gl, hid, Gd + p.down_w);
         gemm_bf16(e->gxb, d, b.wdown_t, d, e->zero_bias, e->dbig, M, hid, d, s);                         // dg = go Wdown
-        hipLaunchKernelGGL(gelu_bwd_kernel, g1((size_t)M * hid / 8), blk, 0, s, e->dbig, b.hc, e->dbig, (size_t)M * hid / 8);      // dhc (in place)
-        if (G <= 16 && N >= 160 && hid % 64 == 0) {      // both images of a (sample, 64-channel chunk) in LDS: each operand is read once (N >= 160: room for the reduction buffer)
-            hipLaunchKernelGGL(dwconv_wgrad_img_kernel, dim3(B * (hid / 64)), blk, (size_t)2 * N * 128, s, e->dbig, b.h, e->part, G, hid);
+        if (G <= 16 && N >= 160 && hid % 64 == 0) {      // GELU' multiply, depthwise weight-gradient partials and input gradient in one pass (both images of a (sample, 64-channel chunk) in LDS)
+            hipLaunchKernelGGL(dwconv_bwd_img_kernel, dim3(B * (hid / 64)), blk, (size_t)2 * N * 128, s, e->dbig, b.hc, b.h, b.dww_t, b.gl, e->part, G, hid);   // dh -> b.gl (its forward value is consumed)
             hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 10 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B, hid);
         } else {
+            hipLaunchKernelGGL(gelu_bwd_kernel, g1((size_t)M * hid / 8), blk, 0, s, e->dbig, b.hc, e->dbig, (size_t)M * hid / 8);      // dhc (in place); b.hc = GELU'(pre-activation)
             hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((hid + 255) / 256, B * G), blk, 0, s, e->dbig, b.h, e->part, G, hid);
             hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 10 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B * G, hid);
+            hipLaunchKernelGGL(dwconv_kernel, dw_grid, blk, dw_lds, s, e->dbig, b.dww_t, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1, dw_rows);   // dh -> b.gl
         }
-        hipLaunchKernelGGL(dwconv_kernel, dw_grid, blk, dw_lds, s, e->dbig, b.dww_t, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1, dw_rows);   // dh -> b.gl (its forward value is consumed)
         colsum(b.gl, M, hid, Gd + p.up_b);
         weight_grad(b.gl, hid, b.a3, d, Gd + p.up_w);
         gemm_bf16(b.gl, hid, b.wup_t, hid, e->zero_bias, e->dsmall2, M, d, hid, s);                     // da3 = dh Wup

@@ -28,6 +28,20 @@ __device__ __forceinline__ float gelu_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
+// GELU(x) and GELU'(x) together, erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 the results are stored in): the
+// polynomial's exp(-z^2), z = x / sqrt(2), is the Gaussian of the derivative's density term, so the pair costs one v_exp and one v_rcp
+// (erff + expf made the separate GELU'-multiply kernel of the backward VALU-bound at 91 us per block).
+__device__ __forceinline__ void gelu_pair(float x, float& g, float& gp) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float E = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);          // exp(-x^2 / 2)
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float half_erfc = 0.5f * poly * E;                                           // 0.5 erfc(|z|)
+    const float phi = x >= 0.f ? 1.0f - half_erfc : half_erfc;                        // Phi(x)
+    g = x * phi;
+    gp = fmaf(x * 0.39894228040143267794f, E, phi);
+}
+
 // ---- small fp32 products (conditioning path, kv projection of the cross-attention, out-projection pieces) ------------------------------
 // C[i, j] (+)= bias[j] + sum_k A(i, k) B(j, k)   with   A(i, k) = A[i sai + k sak],  B(j, k) = B[j sbj + k sbk]:  one kernel serves
 //   forward   out[r, n] = b[n] + sum_k in[r, k] W[n, k]            (A = in, B = W)
@@ -757,9 +771,17 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16* __restrict__ in
     const int ylo = y0 > 0 ? y0 - 1 : 0, yhi = y1 < G ? y1 + 1 : G; // rows staged
     char* smem = smem_ - (size_t)ylo * G * 128;                     // indexed with absolute token numbers below
     const bf16* src = in + (size_t)b * ntok * C + cc * 64;
-    for (int idx = ylo * G * 8 + threadIdx.x; idx < yhi * G * 8; idx += 256) {       // 8 x 16-B pieces per token
-        const int t = idx >> 3, q = idx & 7;
-        *reinterpret_cast<uint4*>(smem + t * 128 + q * 16) = *reinterpret_cast<const uint4*>(src + (size_t)t * C + q * 8);
+    {   // global -> LDS DMA, 8 tokens x 128 B per instruction, every piece of a wave in flight at once (a loop of load + ds_write pairs exposed
+        // one memory round trip per iteration: 113 us per launch at the training shape)
+        typedef const __attribute__((address_space(1))) void* gp_t;
+        typedef __attribute__((address_space(3))) void* lp_t;
+        const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int t0 = ylo * G, pieces = ((yhi - ylo) * G + 7) >> 3;
+        for (int pc = wid; pc < pieces; pc += 4) {
+            int t = t0 + pc * 8 + (lane >> 3);
+            t = t < yhi * G ? t : yhi * G - 1;
+            __builtin_amdgcn_global_load_lds((gp_t)(src + (size_t)t * C + (lane & 7) * 8), (lp_t)(smem + (size_t)(t0 + pc * 8) * 128), 16, 0, 0);
+        }
     }
     const int cq = threadIdx.x & 15;
     const int c0 = cc * 64 + cq * 4;
@@ -768,6 +790,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16* __restrict__ in
     for (int k = 0; k < 9; ++k) wt[k] = *reinterpret_cast<const float4*>(w + (size_t)(flip ? 8 - k : k) * C + c0);    // flipped taps = reversed order
     float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
     if (bias && !flip) bs = *reinterpret_cast<const float4*>(bias + c0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int i = y0 + (threadIdx.x >> 4); i < y1; i += 16) {
         const bool up_ok = i > 0, dn_ok = i + 1 < G;
@@ -796,14 +819,16 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16* __restrict__ in
                 a.w = fmaf(w2.w, R[du].w, fmaf(w1.w, Mc[du].w, fmaf(w0.w, L[du].w, a.w)));
             }
             bf16x4 o;
-            o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w;
-            *reinterpret_cast<bf16x4*>(out + obase + (size_t)j * C) = o;
-            if (gelu_out) {                                   // GELU of the STORED pre-activation: what the backward differentiates
+            if (gelu_out) {                                   // forward: `out` receives GELU'(pre-activation), all the backward needs of it (round 4; it was the
+                const float av[4] = {a.x, a.y, a.z, a.w};     // pre-activation itself, differentiated by a separate VALU-bound pass), `gelu_out` GELU(.)
                 bf16x4 g;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] = (bf16)gelu_exact((float)o[e]);
+                for (int e = 0; e < 4; ++e) { float gv, gd; gelu_pair(av[e], gv, gd); g[e] = (bf16)gv; o[e] = (bf16)gd; }
                 *reinterpret_cast<bf16x4*>(gelu_out + obase + (size_t)j * C) = g;
+            } else {
+                o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w;
             }
+            *reinterpret_cast<bf16x4*>(out + obase + (size_t)j * C) = o;
         };
         float4 c0v[3], c1v[3], c2v[3];
         load_col(-1, c0v);
@@ -818,14 +843,14 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16* __restrict__ in
         if (j < G) { load_col(j + 1, c0v); emit(c1v, c2v, c0v, j); }
     }
 }
-// dhc = dg * GELU'(hc)
-__global__ void gelu_bwd_kernel(const bf16* __restrict__ dg, const bf16* __restrict__ hc, bf16* __restrict__ out, size_t n8) {
+// dhc = dg * gp, gp = GELU'(pre-activation) as the forward stored it (grids the fused backward below does not take)
+__global__ void gelu_bwd_kernel(const bf16* __restrict__ dg, const bf16* __restrict__ gp, bf16* __restrict__ out, size_t n8) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
-    const bf16x8 g = reinterpret_cast<const bf16x8*>(dg)[i], h = reinterpret_cast<const bf16x8*>(hc)[i];
+    const bf16x8 g = reinterpret_cast<const bf16x8*>(dg)[i], h = reinterpret_cast<const bf16x8*>(gp)[i];
     bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)g[e] * gelu_grad((float)h[e]));
+    for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)g[e] * (float)h[e]);
     reinterpret_cast<bf16x8*>(out)[i] = o;
 }
 // weight / bias gradient partials per (sample, image row): part[b G + y][10][C]: taps 0..8, then the bias;  thread per channel, a 3 x 3
@@ -862,13 +887,13 @@ __global__ void dwconv_wgrad_kernel(const bf16* __restrict__ dout, const bf16* _
 #pragma unroll
     for (int k = 0; k < 10; ++k) part[(by * 10 + k) * C + c] = acc[k];
 }
-// The same partials per SAMPLE for grids up to 16 x 16 (the training config): one workgroup = one sample x 64 channels with both images
-// (`in` and `dout`, G x G tokens x 128 B each) brought into LDS by global->LDS DMA, so each operand is read from memory once (the kernel
-// above reads `in` three times with 2-byte accesses and writes / re-reads 250 MB of per-row partials).  A thread owns a channel quad and one
-// image row, slides a 3 x 3 register window of `in` along x, accumulates its 9 taps + bias in fp32, and the 16 rows are then added in a fixed
-// order through LDS: part[b][10][C].
-__global__ __launch_bounds__(256) void dwconv_wgrad_img_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ in, float* __restrict__ part,
-                                                               int G, int C) {
+// The whole backward of GELU + depthwise 3x3 for grids up to 16 x 16 in ONE pass (round 4; it was three: GELU' multiply, weight-gradient partials,
+// input gradient -- 1.4 GB of traffic per block, now 0.8): one workgroup = one sample x 64 channels; the forward input `in` comes into LDS by DMA, the
+// image of dhc = dg * gp (gp = GELU'(pre-activation) from the forward) is formed on the way in.  A thread owns a channel quad and one image row and
+// slides two 3 x 3 register windows along x: `in`'s for its 9 weight-gradient taps + bias, dhc's for the input gradient
+// din[y][x] = sum_taps w[c][ky][kx] dhc[y - ky + 1][x - kx + 1] (tap-major weights read in reverse).  part[b][10][C]: per sample, taps 0..8 then the bias; the 16 rows are added in a fixed order through LDS.
+__global__ __launch_bounds__(256) void dwconv_bwd_img_kernel(const bf16* __restrict__ dg, const bf16* __restrict__ gp, const bf16* __restrict__ in,
+                                                             const float* __restrict__ w, bf16* __restrict__ din, float* __restrict__ part, int G, int C) {
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     typedef const __attribute__((address_space(1))) void* gp_t;
     typedef __attribute__((address_space(3))) void* lp_t;
@@ -878,17 +903,41 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_img_kernel(const bf16* __res
     char* Iin = wsm;                               // [N][64 ch] bf16
     char* Idy = wsm + (size_t)N * 128;
     const int pieces = (N + 7) >> 3;               // 8 tokens x 128 B per DMA instruction
-    for (int pc = wid; pc < 2 * pieces; pc += 4) {
-        const bool second = pc >= pieces;
-        const int q = second ? pc - pieces : pc;
-        int t = q * 8 + (lane >> 3);
+    for (int pc = wid; pc < pieces; pc += 4) {
+        int t = pc * 8 + (lane >> 3);
         t = t < N ? t : N - 1;
-        const bf16* sp = (second ? dout : in) + ((size_t)b * N + t) * C + cc * 64 + (lane & 7) * 8;
-        __builtin_amdgcn_global_load_lds((gp_t)sp, (lp_t)((second ? Idy : Iin) + q * 1024), 16, 0, 0);
+        const bf16* sp = in + ((size_t)b * N + t) * C + cc * 64 + (lane & 7) * 8;
+        __builtin_amdgcn_global_load_lds((gp_t)sp, (lp_t)(Iin + pc * 1024), 16, 0, 0);
+    }
+    for (int base = threadIdx.x; base < N * 8; base += 4 * 256) {           // four 16-byte pieces of each operand in flight per thread
+        bf16x8 a[4], m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256;
+            const int t = idx < N * 8 ? idx >> 3 : N - 1, q = idx & 7;
+            const size_t o = ((size_t)b * N + t) * C + cc * 64 + q * 8;
+            a[u] = *reinterpret_cast<const bf16x8*>(dg + o); m[u] = *reinterpret_cast<const bf16x8*>(gp + o);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256;
+            if (idx >= N * 8) continue;
+            bf16x8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (bf16)((float)a[u][e] * (float)m[u][e]);
+            *reinterpret_cast<bf16x8*>(Idy + (idx >> 3) * 128 + (idx & 7) * 16) = r;
+        }
+    }
+    const int cq = threadIdx.x & 15, y = threadIdx.x >> 4;      // 16 channel quads x up to 16 image rows
+    const int c0 = cc * 64 + cq * 4;
+    f32x2 wt[9][2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(w + (size_t)(8 - k) * C + c0);      // flipped taps = reversed order
+        wt[k][0] = f32x2{t.x, t.y}; wt[k][1] = f32x2{t.z, t.w};
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int cq = threadIdx.x & 15, y = threadIdx.x >> 4;      // 16 channel quads x up to 16 image rows
     f32x2 acc[10][2];
 #pragma unroll
     for (int k = 0; k < 10; ++k) { acc[k][0] = f32x2{0.f, 0.f}; acc[k][1] = f32x2{0.f, 0.f}; }
@@ -899,31 +948,44 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_img_kernel(const bf16* __res
                 v[0] = f32x2{(float)t[0], (float)t[1]}; v[1] = f32x2{(float)t[2], (float)t[3]};
             } else { v[0] = f32x2{0.f, 0.f}; v[1] = f32x2{0.f, 0.f}; }
         };
-        f32x2 w0[3][2], w1[3][2], w2[3][2];
+        f32x2 w0[3][2], w1[3][2], w2[3][2];        // `in`: columns x - 1, x, x + 1 of rows y - 1 .. y + 1
+        f32x2 d0[3][2], d1[3][2], d2[3][2];        // dhc: the same window
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { w0[r][0] = f32x2{0.f, 0.f}; w0[r][1] = f32x2{0.f, 0.f}; ld(Iin, y + r - 1, 0, w1[r]); }
+        for (int r = 0; r < 3; ++r) {
+            w0[r][0] = f32x2{0.f, 0.f}; w0[r][1] = f32x2{0.f, 0.f}; ld(Iin, y + r - 1, 0, w1[r]);
+            d0[r][0] = f32x2{0.f, 0.f}; d0[r][1] = f32x2{0.f, 0.f}; ld(Idy, y + r - 1, 0, d1[r]);
+        }
+        bf16* orow = din + ((size_t)b * N + (size_t)y * G) * C + c0;
         for (int x = 0; x < G; ++x) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) ld(Iin, y + r - 1, x + 1, w2[r]);
-            f32x2 gv[2];
-            ld(Idy, y, x, gv);
+            for (int r = 0; r < 3; ++r) { ld(Iin, y + r - 1, x + 1, w2[r]); ld(Idy, y + r - 1, x + 1, d2[r]); }
+            f32x2 o2[2];
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                acc[9][h2] += gv[h2];
+                const f32x2 gv = d1[1][h2];                    // dhc[y][x]
+                acc[9][h2] += gv;
+                f32x2 o = f32x2{0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    acc[r * 3 + 0][h2] = __builtin_elementwise_fma(gv[h2], w0[r][h2], acc[r * 3 + 0][h2]);
-                    acc[r * 3 + 1][h2] = __builtin_elementwise_fma(gv[h2], w1[r][h2], acc[r * 3 + 1][h2]);
-                    acc[r * 3 + 2][h2] = __builtin_elementwise_fma(gv[h2], w2[r][h2], acc[r * 3 + 2][h2]);
+                    acc[r * 3 + 0][h2] = __builtin_elementwise_fma(gv, w0[r][h2], acc[r * 3 + 0][h2]);
+                    acc[r * 3 + 1][h2] = __builtin_elementwise_fma(gv, w1[r][h2], acc[r * 3 + 1][h2]);
+                    acc[r * 3 + 2][h2] = __builtin_elementwise_fma(gv, w2[r][h2], acc[r * 3 + 2][h2]);
+                    o = __builtin_elementwise_fma(wt[r * 3 + 0][h2], d0[r][h2], o);
+                    o = __builtin_elementwise_fma(wt[r * 3 + 1][h2], d1[r][h2], o);
+                    o = __builtin_elementwise_fma(wt[r * 3 + 2][h2], d2[r][h2], o);
                 }
+                o2[h2] = o;
             }
+            bf16x4 ob;
+            ob[0] = (bf16)o2[0][0]; ob[1] = (bf16)o2[0][1]; ob[2] = (bf16)o2[1][0]; ob[3] = (bf16)o2[1][1];
+            *reinterpret_cast<bf16x4*>(orow + (size_t)x * C) = ob;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) { w0[r][h2] = w1[r][h2]; w1[r][h2] = w2[r][h2]; }
+                for (int h2 = 0; h2 < 2; ++h2) { w0[r][h2] = w1[r][h2]; w1[r][h2] = w2[r][h2]; d0[r][h2] = d1[r][h2]; d1[r][h2] = d2[r][h2]; }
         }
     }
-    __syncthreads();                               // images consumed: their LDS becomes the [16 rows][10][64 ch] reduction buffer (40 KB <= 2 N 128 B for N = 256)
+    __syncthreads();                               // images consumed: their LDS becomes the [16 rows][10][64 ch] reduction buffer (40 KB <= 2 N 128 B for N >= 160)
     float* red = reinterpret_cast<float*>(wsm);
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
