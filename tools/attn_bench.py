@@ -1,5 +1,5 @@
 """Self-attention forward alone (tld_debug_attention_fwd): error against an fp32 torch evaluation of the same bf16 inputs and the HIP-event
-time per launch.  tools/attn_bench.py [--ntok 1024] [--batch 32] [--heads 12] [--iters 20]; TLD_ATTN2=0 selects the round-2 kernel."""
+time per launch.  tools/attn_bench.py [--ntok 1024] [--batch 32] [--heads 12] [--iters 20]."""
 import argparse, ctypes, json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -21,6 +21,11 @@
 // Outputs are row-major bf16 [M, 3 d] (dq | dk | dv), the layout the weight- and input-gradient GEMMs consume.
 #include "tld_common.h"
 
+// attribution builds (tools/attn_bwd_bench.py): -DTLD_AB_DBG=<bits>: 1 no staging loads, 2 no pass 1, 4 no pass 2, 8 no output stores
+#ifndef TLD_AB_DBG
+#define TLD_AB_DBG 0
+#endif
+
 namespace tld {
 
 namespace {
@@ -153,10 +158,13 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16* __restric
 
     // ================================ pass 1: queries [32 wid, 32 wid + 32) of block `blk` ================================
     if (MODE != ATTN_DKV) {
-        stage_rows(sQ, qsrc, 2 * d, blk);
-        stage_g(blk, true);
-        if (MODE == ATTN_FUSED) { stage_rows(sK, ksrc, 2 * d, 0); stage_v(0); }
+        if (!(TLD_AB_DBG & 1)) {
+            stage_rows(sQ, qsrc, 2 * d, blk);
+            stage_g(blk, true);
+            if (MODE == ATTN_FUSED) { stage_rows(sK, ksrc, 2 * d, 0); stage_v(0); }
+        }
         __syncthreads();
+        if (!(TLD_AB_DBG & 2)) {
         const int q0 = 32 * wid;
         bf16x8 qf[4], gf[4];
 #pragma unroll
@@ -252,9 +260,11 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16* __restric
                 dq_accum();
             }
         }
-        store_tile(dqkv + (row0 + (size_t)blk * BT + q0 + l31) * 3 * d + h * 64, dq, 0.125f, hi);
+        if (!(TLD_AB_DBG & 8)) store_tile(dqkv + (row0 + (size_t)blk * BT + q0 + l31) * 3 * d + h * 64, dq, 0.125f, hi);
+        }
     }
     if (MODE == ATTN_DQ) return;
+    if (TLD_AB_DBG & 4) return;
 
     // ================================ pass 2: keys [32 wid, 32 wid + 32) of block `blk` ================================
     if (MODE == ATTN_DKV) { stage_rows(sK, ksrc, 2 * d, blk); stage_v(blk); }
@@ -300,8 +310,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16* __restric
             }
         }
         bf16* dst = dqkv + (row0 + (size_t)blk * BT + k0 + l31) * 3 * d + h * 64;
-        store_tile(dst + d, dk, 0.125f, hi);
-        store_tile(dst + 2 * d, dv, 1.0f, hi);
+        if (!(TLD_AB_DBG & 8)) {
+            store_tile(dst + d, dk, 0.125f, hi);
+            store_tile(dst + 2 * d, dv, 1.0f, hi);
+        }
     }
 }
 
