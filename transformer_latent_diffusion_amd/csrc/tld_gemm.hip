@@ -1385,6 +1385,8 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     pg.half_tail = half_tail ? 1 : 0;
     if ((epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
         pg.xcd_ngroups = 2;
+    // (EPI_QKV_ATTN, round 4: its PMC traffic is 2.6 x algorithmic -- an XCD's round of 32 items wants 2.7 samples' A tiles + all 12 heads' weights,
+    // 4.6 MB against 4 MB of L2 -- but two or four head groups over the XCDs left the kernel at 131.7 us: like the other GEMMs it is not fetch-bound)
 #define TLD_L256P_(E, F8) TLD_L256P__(E, F8, false)
 #define TLD_L256P_LAUNCH(E, F8, CV, RG)                                                               \
     do {                                                                                              \
