@@ -103,9 +103,25 @@ __device__ __forceinline__ f32x2 gelu_erf_fast2(f32x2 x) {
 // delivers y = x / 2):  GELU(x) = y (1 + erf(sqrt2 y)), with sqrt2^i folded into the A&S coefficients.  Two packed
 // multiplies per pair fewer than gelu_erf_fast2(x).
 #ifndef TLD_GELU_POLY4
-#define TLD_GELU_POLY4 1      // 1: erfc by Abramowitz-Stegun 7.1.27 (four coefficients, ^-4, |erf error| <= 5e-4) in the bf16-rounded MLP epilogues;
-#endif                        // 0: 7.1.28 (six coefficients, ^-16, 3e-7).  See DESIGN.md 4.1 for the parity it was judged by.
+#define TLD_GELU_POLY4 2      // 2 (round 4): division-free clamp(y R(y^2)), |GELU error| <= 1.7e-4 incl. the negative tail; fused up-projection 194.6 -> 192.3 us same-box
+#endif                        // 1: erfc by Abramowitz-Stegun 7.1.27 (four coefficients, ^-4, |erf error| <= 5e-4; O(1e-3) absolute on the negative tail);
+                              // 0: 7.1.28 (six coefficients, ^-16, 3e-7).  See DESIGN.md 4.1 for the parity they were judged by.
 __device__ __forceinline__ f32x2 gelu_erf_fast2_half(f32x2 y) {
+#if TLD_GELU_POLY4 == 2
+    // division-free: erf(sqrt2 y) ~ clamp(y R(y^2), -1, 1), R of degree 6 in y^2 (weighted minimax fit on |y| <= 1.98, beyond which the even
+    // polynomial grows and the clamp takes over): |GELU error| <= 1.7e-4 everywhere.  11 packed slots per pair against 18 (two quarter-rate v_rcp).
+    const f32x2 u = y * y;
+    // (Horner; the Estrin form -- three levels instead of six dependent FMAs -- measured no faster: 197.2 us either way)
+    f32x2 r = __builtin_elementwise_fma(f32x2{3.952182666e-04f, 3.952182666e-04f}, u, f32x2{-6.822538060e-03f, -6.822538060e-03f});
+    r = __builtin_elementwise_fma(r, u, f32x2{5.043737174e-02f, 5.043737174e-02f});
+    r = __builtin_elementwise_fma(r, u, f32x2{-2.115262865e-01f, -2.115262865e-01f});
+    r = __builtin_elementwise_fma(r, u, f32x2{5.651242001e-01f, 5.651242001e-01f});
+    r = __builtin_elementwise_fma(r, u, f32x2{-1.035131935e+00f, -1.035131935e+00f});
+    r = __builtin_elementwise_fma(r, u, f32x2{1.591872892e+00f, 1.591872892e+00f});
+    f32x2 e = y * r;
+    e[0] = __builtin_amdgcn_fmed3f(e[0], -1.0f, 1.0f); e[1] = __builtin_amdgcn_fmed3f(e[1], -1.0f, 1.0f);
+    return __builtin_elementwise_fma(y, e, y);
+#endif
     const f32x2 ay = __builtin_elementwise_abs(y);
 #if TLD_GELU_POLY4
     // erfc(sqrt2 |y|) = (1 + b1 |y| + b2 |y|^2 + b3 |y|^3 + b4 |y|^4)^-4,  b_i = a_i sqrt2^i of A&S 7.1.27: four packed FMAs and two
