@@ -26,6 +26,7 @@ using namespace tld::train;
 
 namespace tld {
 int launch_attention_bwd(const bf16* qk, const bf16* vt, const bf16* o, const float* g, bf16* dqkv, float* stats, int batch, int ntok, int heads, hipStream_t s);
+int launch_attention_bwd(const bf16* qk, const bf16* vt, const bf16* o, const bf16* g, bf16* dqkv, float* stats, int batch, int ntok, int heads, hipStream_t s);
 }
 
 namespace {
@@ -519,28 +520,30 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
         colsum(e->gxb, M, d, Gd + p.down_b);
         weight_grad(e->gxb, d, b.gl, hid, Gd + p.down_w);
         gemm_bf16(e->gxb, d, b.wdown_t, d, e->zero_bias, e->dbig, M, hid, d, s);                         // dg = go Wdown
-        if (G <= 16 && N >= 160 && hid % 64 == 0) {      // GELU' multiply, depthwise weight-gradient partials and input gradient in one pass (both images of a (sample, 64-channel chunk) in LDS)
+        const bool dw_fused = G <= 16 && N >= 176 && hid % 64 == 0;
+        if (dw_fused) {      // GELU' multiply, depthwise weight-gradient partials and input gradient in one pass (both images of a (sample, 64-channel chunk) in LDS)
             hipLaunchKernelGGL(dwconv_bwd_img_kernel, dim3(B * (hid / 64)), blk, (size_t)2 * N * 128, s, e->dbig, b.hc, b.h, b.dww_t, b.gl, e->part, G, hid);   // dh -> b.gl (its forward value is consumed)
-            hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 10 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B, hid);
+            hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 11 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B, hid, 11, Gd + p.up_b);   // + the up-projection's bias gradient
         } else {
             hipLaunchKernelGGL(gelu_bwd_kernel, g1((size_t)M * hid / 8), blk, 0, s, e->dbig, b.hc, e->dbig, (size_t)M * hid / 8);      // dhc (in place); b.hc = GELU'(pre-activation)
             hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((hid + 255) / 256, B * G), blk, 0, s, e->dbig, b.h, e->part, G, hid);
             hipLaunchKernelGGL(dwconv_wgrad_reduce, dim3((hid * 10 + 63) / 64), dim3(1024), 0, s, e->part, Gd + p.dw_w, Gd + p.dw_b, B * G, hid);
             hipLaunchKernelGGL(dwconv_kernel, dw_grid, blk, dw_lds, s, e->dbig, b.dww_t, (const float*)nullptr, b.gl, (bf16*)nullptr, B, G, hid, 1, dw_rows);   // dh -> b.gl
         }
-        colsum(b.gl, M, hid, Gd + p.up_b);
+        if (!dw_fused) colsum(b.gl, M, hid, Gd + p.up_b);
         weight_grad(b.gl, hid, b.a3, d, Gd + p.up_w);
         gemm_bf16(b.gl, hid, b.wup_t, hid, e->zero_bias, e->dsmall2, M, d, hid, s);                     // da3 = dh Wup
         ln_bwd_rows(e->dsmall2, b.x3, b.st3, P + p.n3w, e->gx, 1, Gd + p.n3w, Gd + p.n3b, M, d);
         // ---- cross-attention: cr = CA(qc, kv);  qc = a2 Wq^T;  kv = y Wkv^T;  a2 = LN2(x2)
         float* dkv = e->dkv_all + (size_t)i * kv_stride;
-        hipLaunchKernelGGL(cross_bwd_kernel, dim3(B * H), blk, (size_t)2 * N * 4, s, e->gx, b.qc, b.kvc, b.p0, e->dsmall2, dkv, N, d);   // dqc -> dsmall2
+        hipLaunchKernelGGL(cross_bwd_kernel, dim3(B * H), blk, 0, s, e->gx, b.qc, b.kvc, b.p0, e->dsmall2, dkv, N, d);   // dqc -> dsmall2
         lin_dw(dkv, 2 * d, e->y, d, Gd + p.kv, nullptr, 2 * B, 2 * d, d);       // (per block: its gradient range must be complete at the grad_ready call below)
         weight_grad(e->dsmall2, d, b.a2, d, Gd + p.q);
         gemm_bf16(e->dsmall2, d, b.wq_t, d, e->zero_bias, e->dsmall, M, d, d, s);                       // da2 = dqc Wq
         ln_bwd_rows(e->dsmall, b.x2, b.st2, P + p.n2w, e->gx, 1, Gd + p.n2w, Gd + p.n2b, M, d);
         // ---- self-attention: att = SDPA(q, k, v);  qkv = a1 Wqkv^T;  a1 = LN1(x1)
         if (launch_attention_bwd(b.qk, b.vt, b.att, e->gx, e->dsmall, e->attn_stats, B, N, H, s)) return tfail(TLD_ERR_INVALID, "attention backward: unsupported token count %d", N);
+        // (dO as a bf16 copy from the LayerNorm-2 backward: 192 -> 189 us, but delta = dO . O from rounded dO moves the worst g15 gradient from 1.86e-2 to 1.92e-2 of a 2e-2 bound: not taken)
         weight_grad(e->dsmall, 3 * d, b.a1, d, Gd + p.qkv);
         gemm_bf16(e->dsmall, 3 * d, b.wqkv_t, 3 * d, e->zero_bias, e->dsmall2, M, d, 3 * d, s);         // da1 = dqkv Wqkv
         ln_bwd_rows(e->dsmall2, b.x1, b.st1, P + p.n1w, e->gx, 1, Gd + p.n1w, Gd + p.n1b, M, d, i > 0 ? e->gxb : nullptr);

@@ -92,9 +92,9 @@ __device__ __forceinline__ void store_tile(bf16* dst /* row of token l31, first 
         }
 }
 
-template <int NW, int MODE>
+template <int NW, int MODE, typename TG>      // TG: dL/dO as fp32 (the test hook) or bf16 (the training step: the LayerNorm-2 backward leaves a bf16 copy of the residual gradient)
 __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ vt, const bf16* __restrict__ o,
-                                                          const float* __restrict__ g, bf16* __restrict__ dqkv, float* __restrict__ stats, int H, int N) {
+                                                          const TG* __restrict__ g, bf16* __restrict__ dqkv, float* __restrict__ stats, int H, int N) {
     using Ly = Lay<NW>;
     constexpr int BT = Ly::BT, PV = Ly::PV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -117,18 +117,25 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16* __restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) *reinterpret_cast<u32x4*>(img + srow * kPitch + (sc0 + c) * 16) = p[c];
     };
-    auto stage_g = [&](int qb, bool with_delta) {          // dO fp32 -> bf16 image; delta = dO . O per row
+    auto stage_g = [&](int qb, bool with_delta) {          // dO -> bf16 image; delta = dO . O per row
         const size_t row = row0 + (size_t)qb * BT + srow;
-        const float4* pg = reinterpret_cast<const float4*>(g + row * d + h * 64) + sc0 * 2;
         const u32x4* po = reinterpret_cast<const u32x4*>(o + row * d + h * 64) + sc0;
         float delta = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float4 g0 = pg[2 * c], g1 = pg[2 * c + 1];
-            const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             bf16x8 gb;
+            float gv[8];
+            if constexpr (sizeof(TG) == 4) {
+                const float4* pg = reinterpret_cast<const float4*>(g + row * d + h * 64) + sc0 * 2;
+                const float4 g0 = pg[2 * c], g1 = pg[2 * c + 1];
+                const float t[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) gb[e] = (bf16)gv[e];
+                for (int e = 0; e < 8; ++e) { gv[e] = t[e]; gb[e] = (bf16)t[e]; }
+            } else {
+                gb = __builtin_bit_cast(bf16x8, (reinterpret_cast<const u32x4*>(g + row * d + h * 64) + sc0)[c]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gv[e] = (float)gb[e];
+            }
             if (with_delta) {
                 const bf16x8 ob = __builtin_bit_cast(bf16x8, po[c]);
 #pragma unroll
@@ -317,20 +324,17 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16* __restric
     }
 }
 
-template <int NW, int MODE>
-void launch_one(const bf16* qk, const bf16* vt, const bf16* o, const float* g, bf16* dqkv, float* stats, int batch, int ntok, int heads, hipStream_t s) {
+template <int NW, int MODE, typename TG>
+void launch_one(const bf16* qk, const bf16* vt, const bf16* o, const TG* g, bf16* dqkv, float* stats, int batch, int ntok, int heads, hipStream_t s) {
     static PerDeviceOnce once;
     if (once.first())
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<NW, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, Lay<NW>::BYTES);
-    hipLaunchKernelGGL((attn_bwd_kernel<NW, MODE>), dim3(batch * heads * (ntok / (32 * NW))), dim3(64 * NW), Lay<NW>::BYTES, s, qk, vt, o, g, dqkv, stats, heads,
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<NW, MODE, TG>), hipFuncAttributeMaxDynamicSharedMemorySize, Lay<NW>::BYTES);
+    hipLaunchKernelGGL((attn_bwd_kernel<NW, MODE, TG>), dim3(batch * heads * (ntok / (32 * NW))), dim3(64 * NW), Lay<NW>::BYTES, s, qk, vt, o, g, dqkv, stats, heads,
                        ntok);
 }
 
-}  // namespace
-
-// qk [M, 2 d] (q | k) and vt [B, H, 64, N]: the forward's saved operands;  o [M, d]: the forward's output;  g [M, d] fp32: dL/dO;
-// dqkv [M, 3 d] bf16 out.  N = 64, 128 or a multiple of 256; `stats` = 2 B H N floats of scratch, touched only when N > 256.
-int launch_attention_bwd(const bf16* qk, const bf16* vt, const bf16* o, const float* g, bf16* dqkv, float* stats, int batch, int ntok, int heads, hipStream_t s) {
+template <typename TG>
+int launch_bwd(const bf16* qk, const bf16* vt, const bf16* o, const TG* g, bf16* dqkv, float* stats, int batch, int ntok, int heads, hipStream_t s) {
     if (ntok == 256) launch_one<8, ATTN_FUSED>(qk, vt, o, g, dqkv, stats, batch, ntok, heads, s);
     else if (ntok == 128) launch_one<4, ATTN_FUSED>(qk, vt, o, g, dqkv, stats, batch, ntok, heads, s);
     else if (ntok == 64) launch_one<2, ATTN_FUSED>(qk, vt, o, g, dqkv, stats, batch, ntok, heads, s);
@@ -339,6 +343,17 @@ int launch_attention_bwd(const bf16* qk, const bf16* vt, const bf16* o, const fl
         launch_one<8, ATTN_DKV>(qk, vt, o, g, dqkv, stats, batch, ntok, heads, s);
     } else return 1;
     return 0;
+}
+
+}  // namespace
+
+// qk [M, 2 d] (q | k) and vt [B, H, 64, N]: the forward's saved operands;  o [M, d]: the forward's output;  g [M, d]: dL/dO (fp32 or bf16);
+// dqkv [M, 3 d] bf16 out.  N = 64, 128 or a multiple of 256; `stats` = 2 B H N floats of scratch, touched only when N > 256.
+int launch_attention_bwd(const bf16* qk, const bf16* vt, const bf16* o, const float* g, bf16* dqkv, float* stats, int batch, int ntok, int heads, hipStream_t s) {
+    return launch_bwd<float>(qk, vt, o, g, dqkv, stats, batch, ntok, heads, s);
+}
+int launch_attention_bwd(const bf16* qk, const bf16* vt, const bf16* o, const bf16* g, bf16* dqkv, float* stats, int batch, int ntok, int heads, hipStream_t s) {
+    return launch_bwd<bf16>(qk, vt, o, g, dqkv, stats, batch, ntok, heads, s);
 }
 
 }  // namespace tld

@@ -687,12 +687,13 @@ __global__ __launch_bounds__(256) void cross_fwd_kernel(const bf16* __restrict__
     }
 }
 // backward:  g = dL/dout (fp32 [M, d]).  dq -> bf16 [M, d];  dkv[b, t, :] (fp32, written: one workgroup owns a (sample, head) slice)
+// Round 4: the token reductions (dK of token 0 = -dK of token 1, dV0, dV1) are accumulated in the same pass that produces dq -- every thread keeps
+// the partial sums of its feature octet over its token slot, 32 slots are then added in a fixed order through LDS -- instead of a second pass that
+// re-read g and q with 4- / 2-byte loads (67 us per launch).
 __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict__ g, const bf16* __restrict__ q, const float* __restrict__ kv,
                                                         const float* __restrict__ p0_in, bf16* __restrict__ dq, float* __restrict__ dkv, int N, int d) {
     const int H = d >> 6, b = blockIdx.x / H, h = blockIdx.x % H;
-    extern __shared__ float sm[];                 // [N] ds0, [N] p0
-    __shared__ float red[4][3][64];
-    float* ds = sm; float* pp = sm + N;
+    __shared__ float red[32][3][64];              // [token slot][dk0 | dv0 | dv1][feature]
     const int sub = threadIdx.x & 7, tl = threadIdx.x >> 3;
     float kd[8], v0[8], v1[8];
     {
@@ -701,50 +702,45 @@ __global__ __launch_bounds__(256) void cross_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) { kd[e] = kb0[e] - kb1[e]; v0[e] = kb0[d + e]; v1[e] = kb1[d + e]; }
     }
+    float ak[8], a0[8], a1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ak[e] = 0.f; a0[e] = 0.f; a1[e] = 0.f; }
     for (int t = tl; t < N; t += 32) {
         const size_t row = (size_t)b * N + t;
         const f32x4 ga = *reinterpret_cast<const f32x4*>(g + row * d + h * 64 + sub * 8);
         const f32x4 gb = *reinterpret_cast<const f32x4*>(g + row * d + h * 64 + sub * 8 + 4);
+        const bf16x8 q8 = *reinterpret_cast<const bf16x8*>(q + row * d + h * 64 + sub * 8);
+        const float gv[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
         float d0 = 0.f, d1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            d0 = fmaf(ga[e], v0[e], d0); d1 = fmaf(ga[e], v1[e], d1);
-            d0 = fmaf(gb[e], v0[4 + e], d0); d1 = fmaf(gb[e], v1[4 + e], d1);
-        }
+        for (int e = 0; e < 8; ++e) { d0 = fmaf(gv[e], v0[e], d0); d1 = fmaf(gv[e], v1[e], d1); }
 #pragma unroll
         for (int m = 1; m < 8; m <<= 1) { d0 += __shfl_xor(d0, m, 64); d1 += __shfl_xor(d1, m, 64); }
         const float p0 = p0_in[row * H + h];
         const float s0 = p0 * (1.0f - p0) * (d0 - d1) * 0.125f;            // dL/ds0 = -dL/ds1, with the 1/8 score scale
-        if (sub == 0) { ds[t] = s0; pp[t] = p0; }
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)(s0 * kd[e]);
+        for (int e = 0; e < 8; ++e) {
+            o[e] = (bf16)(s0 * kd[e]);
+            ak[e] = fmaf(s0, (float)q8[e], ak[e]);
+            a0[e] = fmaf(p0, gv[e], a0[e]);
+            a1[e] = fmaf(1.0f - p0, gv[e], a1[e]);
+        }
         *reinterpret_cast<bf16x8*>(dq + row * d + h * 64 + sub * 8) = o;
     }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tl][0][sub * 8 + e] = ak[e]; red[tl][1][sub * 8 + e] = a0[e]; red[tl][2][sub * 8 + e] = a1[e]; }
     __syncthreads();
-    // reductions over the sample's tokens: feature i of this head, tokens split over the four waves (added in a fixed order afterwards)
-    {
-        const int i = threadIdx.x & 63, part = threadIdx.x >> 6;
-        float dk0 = 0.f, dv0 = 0.f, dv1 = 0.f;
-        for (int t = part; t < N; t += 4) {
-            const size_t row = (size_t)b * N + t;
-            const float gi = g[row * d + h * 64 + i];
-            dk0 = fmaf(ds[t], (float)q[row * d + h * 64 + i], dk0);
-            dv0 = fmaf(pp[t], gi, dv0);
-            dv1 = fmaf(1.0f - pp[t], gi, dv1);
-        }
-        red[part][0][i] = dk0; red[part][1][i] = dv0; red[part][2][i] = dv1;
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int i = threadIdx.x;
-        const float dk0 = (red[0][0][i] + red[1][0][i]) + (red[2][0][i] + red[3][0][i]);
-        const float dv0 = (red[0][1][i] + red[1][1][i]) + (red[2][1][i] + red[3][1][i]);
-        const float dv1 = (red[0][2][i] + red[1][2][i]) + (red[2][2][i] + red[3][2][i]);
+    if (threadIdx.x < 192) {
+        const int i = threadIdx.x & 63, k = threadIdx.x >> 6;
+        float t = 0.f;
+#pragma unroll 8
+        for (int sl = 0; sl < 32; ++sl) t += red[sl][k][i];
         float* o0 = dkv + ((size_t)b * 2 + 0) * 2 * d;
         float* o1 = dkv + ((size_t)b * 2 + 1) * 2 * d;
-        o0[h * 64 + i] = dk0; o1[h * 64 + i] = -dk0;
-        o0[d + h * 64 + i] = dv0; o1[d + h * 64 + i] = dv1;
+        if (k == 0) { o0[h * 64 + i] = t; o1[h * 64 + i] = -t; }
+        else if (k == 1) o0[d + h * 64 + i] = t;
+        else o1[d + h * 64 + i] = t;
     }
 }
 
@@ -938,9 +934,9 @@ __global__ __launch_bounds__(256) void dwconv_bwd_img_kernel(const bf16* __restr
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    f32x2 acc[10][2];
+    f32x2 acc[11][2];                              // 9 taps, the depthwise bias, and the column sum of din (= the up-projection's bias gradient)
 #pragma unroll
-    for (int k = 0; k < 10; ++k) { acc[k][0] = f32x2{0.f, 0.f}; acc[k][1] = f32x2{0.f, 0.f}; }
+    for (int k = 0; k < 11; ++k) { acc[k][0] = f32x2{0.f, 0.f}; acc[k][1] = f32x2{0.f, 0.f}; }
     if (y < G) {
         auto ld = [&](const char* img, int yy, int xx, f32x2 (&v)[2]) {
             if ((unsigned)yy < (unsigned)G && (unsigned)xx < (unsigned)G) {
@@ -975,6 +971,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_img_kernel(const bf16* __restr
                     o = __builtin_elementwise_fma(wt[r * 3 + 2][h2], d2[r][h2], o);
                 }
                 o2[h2] = o;
+                acc[10][h2] += o;
             }
             bf16x4 ob;
             ob[0] = (bf16)o2[0][0]; ob[1] = (bf16)o2[0][1]; ob[2] = (bf16)o2[1][0]; ob[3] = (bf16)o2[1][1];
@@ -985,36 +982,37 @@ __global__ __launch_bounds__(256) void dwconv_bwd_img_kernel(const bf16* __restr
                 for (int h2 = 0; h2 < 2; ++h2) { w0[r][h2] = w1[r][h2]; w1[r][h2] = w2[r][h2]; d0[r][h2] = d1[r][h2]; d1[r][h2] = d2[r][h2]; }
         }
     }
-    __syncthreads();                               // images consumed: their LDS becomes the [16 rows][10][64 ch] reduction buffer (40 KB <= 2 N 128 B for N >= 160)
+    __syncthreads();                               // images consumed: their LDS becomes the [16 rows][11][64 ch] reduction buffer (44 KB <= 2 N 128 B for N >= 176)
     float* red = reinterpret_cast<float*>(wsm);
 #pragma unroll
-    for (int k = 0; k < 10; ++k) {
-        float* dst = red + ((size_t)y * 10 + k) * 64 + cq * 4;
+    for (int k = 0; k < 11; ++k) {
+        float* dst = red + ((size_t)y * 11 + k) * 64 + cq * 4;
         *reinterpret_cast<f32x4*>(dst) = f32x4{acc[k][0][0], acc[k][0][1], acc[k][1][0], acc[k][1][1]};
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 640; i += 256) {                 // (tap k, channel c) of this chunk; rows added in order
+    for (int i = threadIdx.x; i < 704; i += 256) {                 // (slot k, channel c) of this chunk; rows added in order
         float t = 0.f;
-        for (int r = 0; r < 16; ++r) t += red[(size_t)r * 640 + i];
+        for (int r = 0; r < 16; ++r) t += red[(size_t)r * 704 + i];
         const int k = i >> 6, c = i & 63;
-        part[((size_t)b * 10 + k) * C + cc * 64 + c] = t;
+        part[((size_t)b * 11 + k) * C + cc * 64 + c] = t;
     }
 }
-// dw [C, 9] / db [C] from part[nparts][10][C]  (64 (tap, channel) outputs x 16 part-lanes per workgroup, fixed order)
-__global__ __launch_bounds__(1024) void dwconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nparts, int C) {
+// dw [C, 9] / db [C] (/ db2 [C]: slot 10, when nslot == 11) from part[nparts][nslot][C]  (64 (slot, channel) outputs x 16 part-lanes per workgroup, fixed order)
+__global__ __launch_bounds__(1024) void dwconv_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nparts, int C,
+                                                            int nslot = 10, float* __restrict__ db2 = nullptr) {
     __shared__ float red[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + tx;                 // over 10 * C, channel fastest
+    const int i = blockIdx.x * 64 + tx;                 // over nslot * C, channel fastest
     float a = 0.f;
-    if (i < 10 * C) for (int p = ty; p < nparts; p += 16) a += part[(size_t)p * 10 * C + i];
+    if (i < nslot * C) for (int p = ty; p < nparts; p += 16) a += part[(size_t)p * nslot * C + i];
     red[ty][tx] = a;
     __syncthreads();
-    if (ty == 0 && i < 10 * C) {
+    if (ty == 0 && i < nslot * C) {
         float t = 0.f;
 #pragma unroll
         for (int l = 0; l < 16; ++l) t += red[l][tx];
         const int c = i % C, k = i / C;
-        if (k < 9) dw[c * 9 + k] = t; else db[c] = t;
+        if (k < 9) dw[c * 9 + k] = t; else if (k == 9) db[c] = t; else db2[c] = t;
     }
 }
 
