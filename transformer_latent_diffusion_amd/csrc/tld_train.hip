@@ -239,7 +239,7 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
         if (((M + 63) / 64) * (size_t)wide > need) need = ((M + 63) / 64) * (size_t)wide;     // column-sum partials (64-row chunks)
         e->splitk_floats = 8 * (size_t)wide * d;
         DALLOC(e->splitk, e->splitk_floats);
-        if (nchunk * (size_t)pd * d > need) need = nchunk * (size_t)pd * d;    // tall weight-gradient partials
+        if (((M + 63) / 64) * (size_t)pd * d > need) need = ((M + 63) / 64) * (size_t)pd * d;    // tall weight-gradient partials (64-row chunks)
         e->part_floats = need;
         DALLOC(e->part, need);
         e->lb.resize(e->L);
@@ -433,6 +433,21 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
     auto reduce = [&](int nparts, size_t stride, size_t part_off, float* dst, int n, int acc) {
         hipLaunchKernelGGL(reduce_partials, dim3((n + 15) / 16), dim3(1024), 0, s, e->part + part_off, nparts, stride, dst, n, acc);
     };
+    // dW[Nn, K] = dy^T x over the M rows (dy fp32 [M, Nn], Nn = patch_dim or smaller; x [M, K]) -> dst (fixed-order sum of per-chunk partials)
+    auto tall_dw = [&](const float* dyp, int Nn, auto xp, int K, float* dst) {
+        using TX = std::remove_cv_t<std::remove_pointer_t<decltype(xp)>>;
+        const int nc64 = (M + 63) / 64;
+        if ((Nn == 16 || Nn == 32 || Nn == 64) && (size_t)nc64 * Nn * K <= e->part_floats) {
+            const dim3 grid((K + 255) / 256, nc64);
+            if (Nn == 16) hipLaunchKernelGGL((tall_dw_cols_partial<TX, 16>), grid, blk, 0, s, dyp, xp, K, M, 64, e->part);
+            else if (Nn == 32) hipLaunchKernelGGL((tall_dw_cols_partial<TX, 32>), grid, blk, 0, s, dyp, xp, K, M, 64, e->part);
+            else hipLaunchKernelGGL((tall_dw_cols_partial<TX, 64>), grid, blk, 0, s, dyp, xp, K, M, 64, e->part);
+            reduce(nc64, (size_t)Nn * K, 0, dst, Nn * K, 0);
+        } else {
+            hipLaunchKernelGGL((tall_dw_partial<TX>), dim3((Nn * K + 255) / 256, nchunk), blk, 0, s, dyp, Nn, xp, K, M, 256, e->part);
+            reduce(nchunk, (size_t)Nn * K, 0, dst, Nn * K, 0);
+        }
+    };
     auto ln_bwd_rows = [&](auto dyp, auto xp, const float2* st, const float* gamma, float* dx, int acc, float* dgamma, float* dbeta, int rows, int width,
                            bf16* dxb = nullptr) {
         using TDY = std::remove_cv_t<std::remove_pointer_t<decltype(dyp)>>;
@@ -508,9 +523,12 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
     };
 
     // out_proj: gx = dout Wout;  dWout = dout^T x_final;  dbout
-    hipLaunchKernelGGL(tail_dx_kernel, g1((size_t)M * d), blk, 0, s, e->dout, P + e->outw, e->gx, e->gxb, M, pd, d);      // gx and its bf16 copy (the top block's GEMM operand)
-    hipLaunchKernelGGL((tall_dw_partial<bf16>), dim3((pd * d + 255) / 256, nchunk), blk, 0, s, e->dout, pd, e->xfin, d, M, 256, e->part);
-    reduce(nchunk, (size_t)pd * d, 0, Gd + e->outw, pd * d, 0);
+    // gx and its bf16 copy (the top block's GEMM operand)
+    if (pd == 16) hipLaunchKernelGGL((tail_dx4_kernel<16>), g1((size_t)M * d / 4), blk, 0, s, e->dout, P + e->outw, e->gx, e->gxb, M, d);
+    else if (pd == 32) hipLaunchKernelGGL((tail_dx4_kernel<32>), g1((size_t)M * d / 4), blk, 0, s, e->dout, P + e->outw, e->gx, e->gxb, M, d);
+    else if (pd == 64) hipLaunchKernelGGL((tail_dx4_kernel<64>), g1((size_t)M * d / 4), blk, 0, s, e->dout, P + e->outw, e->gx, e->gxb, M, d);
+    else hipLaunchKernelGGL(tail_dx_kernel, g1((size_t)M * d), blk, 0, s, e->dout, P + e->outw, e->gx, e->gxb, M, pd, d);
+    tall_dw(e->dout, pd, (const bf16*)e->xfin, d, Gd + e->outw);
     colsum(e->dout, M, pd, Gd + e->outb);
 
     for (int i = e->L - 1; i >= 0; --i) {
@@ -560,15 +578,13 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
     ln_bwd_rows(e->gx, e->e, e->est2, P + e->l2w, e->de, 0, Gd + e->l2w, Gd + e->l2b, M, d);
     colsum(e->de, M, d, Gd + e->lib);
     lin_dx(e->de, d, P + e->liw, e->dpn, pd, M, d, pd, 0);               // dpn = de Wlin
-    hipLaunchKernelGGL((tall_dw_partial<float>), dim3((pd * d + 255) / 256, nchunk), blk, 0, s, e->p16n, pd, e->de, d, M, 256, e->part);
-    reduce(nchunk, (size_t)pd * d, 0, e->scr, pd * d, 0);                                                                              // dWlin^T [pd, d]
+    tall_dw(e->p16n, pd, (const float*)e->de, d, e->scr);                                                                              // dWlin^T [pd, d]
     hipLaunchKernelGGL(transpose_f32_small, g1((size_t)pd * d), blk, 0, s, e->scr, Gd + e->liw, pd, d);
     hipLaunchKernelGGL(ln_small_bwd_kernel, dim3(nchunk), blk, 0, s, e->dpn, e->p16, e->est1, P + e->l1w, e->dp16, e->part, M, pd);
     reduce(nchunk, 2 * (size_t)pd, 0, Gd + e->l1w, pd, 0);
     reduce(nchunk, 2 * (size_t)pd, pd, Gd + e->l1b, pd, 0);
     hipLaunchKernelGGL(patches_kernel, g1((size_t)M * pd), blk, 0, s, x_noisy, e->patches, B, e->C, e->S, e->cfg.patch_size, G);
-    hipLaunchKernelGGL((tall_dw_partial<float>), dim3((pd * pd + 255) / 256, nchunk), blk, 0, s, e->dp16, pd, e->patches, pd, M, 256, e->part);
-    reduce(nchunk, (size_t)pd * pd, 0, Gd + e->cvw, pd * pd, 0);
+    tall_dw(e->dp16, pd, (const float*)e->patches, pd, Gd + e->cvw);
     colsum(e->dp16, M, pd, Gd + e->cvb);
     // ---- conditioning: y = LN(stack[nz, lb]);  nz = W3 GELU(W1 sin + b1) + b3;  lb = label_proj(label)     (tld/denoiser.py:105-122)
     ln_bwd_rows(e->dy, e->ycat, e->yst, P + e->nw, e->dycat, 0, Gd + e->nw, Gd + e->nb, 2 * B, d);

@@ -1067,6 +1067,27 @@ __global__ void tail_dx_kernel(const float* __restrict__ dout, const float* __re
     gx[i] = a;
     gx_bf16[i] = (bf16)a;
 }
+// four consecutive columns per thread (d % 4 == 0): 16-byte weight loads and stores, the row's dout values as wave-uniform 16-byte loads
+template <int PD>
+__global__ __launch_bounds__(256) void tail_dx4_kernel(const float* __restrict__ dout, const float* __restrict__ W, float* __restrict__ gx, bf16* __restrict__ gx_bf16,
+                                                       int M, int d) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = d >> 2;
+    if (i >= (size_t)M * q) return;
+    const int c = (int)(i % q) * 4;
+    const size_t row = i / q;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f4 = 0; f4 < PD / 4; ++f4) {
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dout + row * PD + 4 * f4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a = __builtin_elementwise_fma(f32x4{dv[e], dv[e], dv[e], dv[e]}, ldf4(W + (size_t)(4 * f4 + e) * d + c), a);
+    }
+    *reinterpret_cast<f32x4*>(gx + row * d + c) = a;
+    bf16x4 o;
+    o[0] = (bf16)a[0]; o[1] = (bf16)a[1]; o[2] = (bf16)a[2]; o[3] = (bf16)a[3];
+    *reinterpret_cast<bf16x4*>(gx_bf16 + row * d + c) = o;
+}
 // generic "tall" weight gradient with a SMALL output (out-projection, patch Linear, patch conv):
 // part[chunk][n][k] = sum_{rows of chunk} dy[r, n] x[r, k];  n < Nn <= 64, thread per (n, k);  dy fp32, x bf16 or fp32
 template <typename TX>
@@ -1078,6 +1099,31 @@ __global__ void tall_dw_partial(const float* __restrict__ dy, int Nn, const TX* 
     float a = 0.f;
     for (int r = r0; r < r1; ++r) a = fmaf(dy[(size_t)r * Nn + n], ldf(x + (size_t)r * K + k), a);
     part[(size_t)blockIdx.y * Nn * K + i] = a;
+}
+// The same partials with a thread per x-column computing ALL NN outputs of its column: x is read once instead of NN times through L2 (the form
+// above took 232 / 140 us for the out-projection / patch-embedding weights at the training shape), dy rows are wave-uniform 16-byte loads.
+template <typename TX, int NN>
+__global__ __launch_bounds__(256) void tall_dw_cols_partial(const float* __restrict__ dy, const TX* __restrict__ x, int K, int M, int rows_per_chunk,
+                                                            float* __restrict__ part) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float a[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) a[n] = 0.f;
+#pragma unroll 4
+    for (int r = r0; r < r1; ++r) {
+        const float xv = ldf(x + (size_t)r * K + k);
+        const float4* dr = reinterpret_cast<const float4*>(dy + (size_t)r * NN);
+#pragma unroll
+        for (int n4 = 0; n4 < NN / 4; ++n4) {
+            const float4 d4 = dr[n4];
+            a[4 * n4 + 0] = fmaf(d4.x, xv, a[4 * n4 + 0]); a[4 * n4 + 1] = fmaf(d4.y, xv, a[4 * n4 + 1]);
+            a[4 * n4 + 2] = fmaf(d4.z, xv, a[4 * n4 + 2]); a[4 * n4 + 3] = fmaf(d4.w, xv, a[4 * n4 + 3]);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NN; ++n) part[(size_t)blockIdx.y * NN * K + (size_t)n * K + k] = a[n];
 }
 
 // ---- sinusoidal embedding (tld/transformer_blocks.py:7-21) -------------------------------------------------------------------------
