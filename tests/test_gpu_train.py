@@ -100,13 +100,13 @@ def test_adam_and_ema_kernel_vs_reference_update():
     assert tr.step == 2 and tr.checkpoint()["global_step"] == 2
 
 
-@pytest.mark.parametrize("N", [64, 128, 256, 1024])
+@pytest.mark.parametrize("N", [64, 128, 256, 1024, 4096])
 def test_attention_backward_vs_autograd(N):
     """tld_debug_attention_bwd against torch autograd of softmax(q k^T / 8) v on the same bf16-rounded operands: dq, dk, dv <= 2e-2.
     64 / 128 / 256 tokens: one workgroup per (sample, head); 1024: the two-kernel path (row statistics through the scratch vector).
     Asymmetric random operands, so a transposed or mis-ordered fragment cannot cancel."""
     from transformer_latent_diffusion_amd import _lib
-    B, H = 3, 2
+    B, H = (3, 2) if N < 4096 else (1, 2)
     d = 64 * H
     gen = torch.Generator().manual_seed(9)
     q, k, v = (torch.randn(B, N, d, generator=gen).bfloat16().float() for _ in range(3))
@@ -180,6 +180,31 @@ def test_64_token_step_vs_oracle_autograd():
     assert rel_rms(pred.cpu().numpy(), pred_ref.numpy()) <= FWD_TOL
     got = {k: v.cpu().numpy() for k, v in tr.grad_dict().items()}
     _check_grads(got, {k: grads_ref[k].numpy() for k in got}, "64-token model vs oracle autograd")
+
+
+def test_4096_token_step_vs_oracle_autograd():
+    """image_size 128 (64 x 64 grid, 4096 tokens: the 1024 px fine-tuning geometry), one block, two samples: 16 query / key blocks in the two-kernel
+    attention backward, four row bands in the depthwise convolution; every gradient vs autograd over the pinned restatement."""
+    from oracle.torch_ref import train_step_reference
+    from transformer_latent_diffusion_amd import DenoiserConfig
+    from transformer_latent_diffusion_amd.train import drop_labels, mix_noise
+    from transformer_latent_diffusion_amd.weights import synth_state_dict
+    cfg = DenoiserConfig(image_size=128, n_channels=4, n_layers=1)
+    sd = synth_state_dict(cfg, 43)
+    gen = torch.Generator().manual_seed(44)
+    B = 2
+    x = torch.randn(B, 4, 128, 128, generator=gen) * 0.8
+    y = torch.randn(B, 768, generator=gen) * 0.5
+    nl = torch.tensor([0.2, 0.7], dtype=torch.float64)
+    noise = torch.randn(B, 4, 128, 128, generator=gen)
+    mask = torch.tensor([False, True])
+    loss_ref, pred_ref, grads_ref = train_step_reference(cfg, sd, x, nl, noise, y, mask)
+    tr = _trainer(cfg, sd, max_batch=2)
+    loss, pred = tr.forward_backward(mix_noise(x, nl, noise), nl.float(), drop_labels(y, mask), x)
+    assert abs(float(loss) - loss_ref) <= 5e-3 * loss_ref, (float(loss), loss_ref)
+    assert rel_rms(pred.cpu().numpy(), pred_ref.numpy()) <= FWD_TOL
+    got = {k: v.cpu().numpy() for k, v in tr.grad_dict().items()}
+    _check_grads(got, {k: grads_ref[k].numpy() for k in got}, "4096-token model vs oracle autograd")
 
 
 def test_wide_model_gradients_vs_oracle_autograd():

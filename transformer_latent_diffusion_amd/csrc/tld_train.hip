@@ -306,8 +306,7 @@ int tld_train_refresh_weights(tld_train* e, void* hip_stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     const int d = e->d, hid = e->hid;
     auto both = [&](int64_t off, int R, int Cc, bf16* w, bf16* wt) {       // [R, C] fp32 -> bf16 copy and bf16 transpose [C, R]
-        hipLaunchKernelGGL(cast_f32_bf16, g1((size_t)R * Cc), dim3(256), 0, s, e->params + off, w, (size_t)R * Cc);
-        hipLaunchKernelGGL((transpose_to_bf16<float>), dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, e->params + off, Cc, wt, R, R, Cc);
+        hipLaunchKernelGGL((transpose_to_bf16<float>), dim3((Cc + 31) / 32, (R + 31) / 32), dim3(256), 0, s, e->params + off, Cc, wt, R, R, Cc, 1, w);
     };
     for (int i = 0; i < e->L; ++i) {
         both(e->lp[i].qkv, 3 * d, d, e->lb[i].wqkv, e->lb[i].wqkv_t);

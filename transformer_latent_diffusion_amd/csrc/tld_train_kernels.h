@@ -433,7 +433,8 @@ __global__ __launch_bounds__(256) void resid_add_ln_kernel(const bf16* __restric
 // ---- layout helpers -----------------------------------------------------------------------------------------------------------
 // [R, C] -> [C, R] (bf16 out), 32 x 32 tiles through LDS;  TIN = bf16 or float (rounded once)
 template <typename TIN>
-__global__ __launch_bounds__(256) void transpose_to_bf16(const TIN* __restrict__ in, int ldi, bf16* __restrict__ out, int ldo, int R, int C, int splits = 1) {
+__global__ __launch_bounds__(256) void transpose_to_bf16(const TIN* __restrict__ in, int ldi, bf16* __restrict__ out, int ldo, int R, int C, int splits = 1,
+                                                         bf16* __restrict__ copy = nullptr /* optional [R, C] bf16 copy of the input (the weight refresh: one pass for both operand forms) */) {
     // splits > 1 (split-K operand of a weight-gradient GEMM): the R rows are cut into `splits` equal runs and the output is the stack
     // [split][C][R / splits] -- ldo = R / splits then
     __shared__ float tile[32][33];
@@ -441,7 +442,9 @@ __global__ __launch_bounds__(256) void transpose_to_bf16(const TIN* __restrict__
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
     for (int i = ty; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? ldf(in + (size_t)r * ldi + c) : 0.f;
+        const float v = (r < R && c < C) ? ldf(in + (size_t)r * ldi + c) : 0.f;
+        tile[i][tx] = v;
+        if (copy && r < R && c < C) copy[(size_t)r * C + c] = (bf16)v;
     }
     __syncthreads();
     const int rs = R / splits;
@@ -478,20 +481,6 @@ __global__ __launch_bounds__(256) void transpose_bf16_64(const bf16* __restrict_
         for (int e = 0; e < 8; ++e) v[e] = tile[ch * 8 + e][c];
         *reinterpret_cast<bf16x8*>(out + ((size_t)sp * C + c0 + c) * ldo + (r0 - sp * rs) + ch * 8) = v;
     }
-}
-__global__ void cast_f32_bf16(const float* __restrict__ in, bf16* __restrict__ out, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (bf16)in[i];
-}
-// V^T [B, H, 64, N] (the attention kernel's operand) -> v row-major [B N, d]
-__global__ void vt_to_rows(const bf16* __restrict__ vt, bf16* __restrict__ v, int B, int H, int N) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // over B * N * d, feature fastest
-    const int d = H * 64;
-    if (i >= (size_t)B * N * d) return;
-    const int f = (int)(i % d);
-    const size_t m = i / d;
-    const int b = (int)(m / N), t = (int)(m % N);
-    v[i] = vt[(((size_t)b * H + (f >> 6)) * 64 + (f & 63)) * N + t];
 }
 
 // ---- patch embedding (tld/denoiser.py:34-45,75-77) ------------------------------------------------------------------------------
