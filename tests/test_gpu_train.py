@@ -182,6 +182,32 @@ def test_64_token_step_vs_oracle_autograd():
     _check_grads(got, {k: grads_ref[k].numpy() for k in got}, "64-token model vs oracle autograd")
 
 
+@pytest.mark.parametrize("d", [192, 320])
+def test_odd_width_step_vs_oracle_autograd(d):
+    """embed_dim a multiple of 64 that is not one of 128 (3 / 5 heads; the reference's own domain, transformer_blocks.py:126-128): 128-wide GEMM tiles
+    with partial last tiles, the transposing weight-gradient path, 2-byte row kernels; every gradient vs autograd over the pinned restatement."""
+    from oracle.torch_ref import train_step_reference
+    from transformer_latent_diffusion_amd import DenoiserConfig
+    from transformer_latent_diffusion_amd.train import drop_labels, mix_noise
+    from transformer_latent_diffusion_amd.weights import synth_state_dict
+    cfg = DenoiserConfig(image_size=32, n_channels=4, n_layers=2, embed_dim=d)
+    sd = synth_state_dict(cfg, 45 + d)
+    gen = torch.Generator().manual_seed(46)
+    B = 4
+    x = torch.randn(B, 4, 32, 32, generator=gen) * 0.8
+    y = torch.randn(B, 768, generator=gen) * 0.5
+    nl = torch.tensor([0.1, 0.35, 0.6, 0.85], dtype=torch.float64)
+    noise = torch.randn(B, 4, 32, 32, generator=gen)
+    mask = torch.tensor([False, False, True, False])
+    loss_ref, pred_ref, grads_ref = train_step_reference(cfg, sd, x, nl, noise, y, mask)
+    tr = _trainer(cfg, sd, max_batch=4)
+    loss, pred = tr.forward_backward(mix_noise(x, nl, noise), nl.float(), drop_labels(y, mask), x)
+    assert abs(float(loss) - loss_ref) <= 5e-3 * loss_ref, (float(loss), loss_ref)
+    assert rel_rms(pred.cpu().numpy(), pred_ref.numpy()) <= FWD_TOL
+    got = {k: v.cpu().numpy() for k, v in tr.grad_dict().items()}
+    _check_grads(got, {k: grads_ref[k].numpy() for k in got}, f"d = {d} model vs oracle autograd")
+
+
 def test_4096_token_step_vs_oracle_autograd():
     """image_size 128 (64 x 64 grid, 4096 tokens: the 1024 px fine-tuning geometry), one block, two samples: 16 query / key blocks in the two-kernel
     attention backward, four row bands in the depthwise convolution; every gradient vs autograd over the pinned restatement."""

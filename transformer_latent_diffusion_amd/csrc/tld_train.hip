@@ -175,7 +175,7 @@ int tld_train_create(const tld_config* cfg, tld_train** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return tfail(TLD_ERR_HIP, "no HIP device: the training engine has no CPU path");
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return tfail(TLD_ERR_INVALID, "device_id %d out of range", cfg->device_id);
-    if (cfg->embed_dim % 128 || cfg->embed_dim > 1024 || cfg->embed_dim <= 0) return tfail(TLD_ERR_INVALID, "embed_dim must be a multiple of 128, <= 1024");
+    if (cfg->embed_dim % 64 || cfg->embed_dim > 1024 || cfg->embed_dim <= 0) return tfail(TLD_ERR_INVALID, "embed_dim must be a multiple of 64 (the head width), <= 1024");
     if (cfg->patch_size <= 0 || cfg->image_size % cfg->patch_size) return tfail(TLD_ERR_INVALID, "image_size must be a multiple of patch_size");
     const int G = cfg->image_size / cfg->patch_size;
     // token counts the attention kernels are built for (forward: launch_attention; backward: tld_train_attn.hip); the reference trains at
