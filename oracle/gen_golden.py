@@ -341,6 +341,11 @@ SWEEP_CASES = [
     ("n64_d768", dict(image_size=16, embed_dim=768)),
     ("n1024_d256", dict(image_size=64, embed_dim=256)),                          # 1024 tokens
     ("n1024_d384", dict(image_size=64, embed_dim=384)),
+    # grids whose side is a multiple of 4 but whose token count has no shape-specialised attention kernel (masked chunked kernel)
+    ("n16_d128", dict(image_size=8, embed_dim=128)),                             # 4 x 4 tokens
+    ("n144_d256", dict(image_size=24, embed_dim=256)),                           # 12 x 12
+    ("n400_d384", dict(image_size=40, embed_dim=384)),                           # 20 x 20: three full 128-key chunks + 16 keys
+    ("n576_d768", dict(image_size=48, embed_dim=768)),                           # 24 x 24 at the 100 M width (LayerNorm folds on, tiled depthwise kernel)
 ]
 
 

@@ -44,7 +44,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr float kScaleLog2e = 0.125f * 1.44269504088896340736f;   // (1/sqrt(64)) * log2(e)
 
-template <int KT, int NW>   // 32-key tiles per chunk; NW waves (32 query rows each) per workgroup
+// MASK (any token count that is a multiple of 8 -- grids the reference accepts and the shape-specialised kernels do not take, e.g. 12 x 12 or
+// 20 x 20): the last key chunk and the last query block are partial; keys past ntok score -inf (their K rows are the sample's last row, their
+// V^T values zero), query rows past ntok are computed on the last row and not stored.
+template <int KT, int NW, bool MASK = false>   // 32-key tiles per chunk; NW waves (32 query rows each) per workgroup
 __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ qk,
                                                        const bf16* __restrict__ vt,
                                                        bf16* __restrict__ att, int ntok, int d, int nbuf) {
@@ -71,7 +74,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
     // Q fragments (B operand of S^T = K Q^T): lane holds q-row l31, features ks*16 + hi*8 .. +8
     bf16x8 qf[4];
     {
-        const bf16* qp = qk + (row_base + q0 + l31) * twod + h * 64 + hi * 8;
+        const int qrow = MASK ? (q0 + l31 < ntok ? q0 + l31 : ntok - 1) : q0 + l31;
+        const bf16* qp = qk + (row_base + qrow) * twod + h * 64 + hi * 8;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
     }
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
         for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int nchunks = ntok / KC;
+    const int nchunks = MASK ? (ntok + KC - 1) / KC : ntok / KC;
     constexpr int KP = KC / 8 / NW;              // 8-row K DMA pieces per wave
     constexpr int PIECES = 64 * (KC / 8);
     constexpr int PER_THREAD = PIECES / (NW * 64);
@@ -94,7 +98,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
         for (int it = 0; it < KP; ++it) {
             const int r = (wid * KP + it) * 8 + (lane >> 3);
             const int clog = (lane & 7) ^ ((r >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (size_t)r * twod + clog * 8), (lptr_t)(Ks + (wid * KP + it) * 1024), 16, 0, 0);
+            const int rs = MASK ? (ch * KC + r < ntok ? r : ntok - 1 - ch * KC) : r;        // (the image position stays r)
+            __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (ptrdiff_t)rs * twod + clog * 8), (lptr_t)(Ks + (wid * KP + it) * 1024), 16, 0, 0);
         }
     };
     u32x4 vreg[PER_THREAD];
@@ -104,7 +109,8 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
         for (int it = 0; it < PER_THREAD; ++it) {
             const int pidx = it * (NW * 64) + threadIdx.x;
             const int c = pidx / (KC / 8), kc8 = pidx % (KC / 8);
-            vreg[it] = *reinterpret_cast<const u32x4*>(vbase + (size_t)c * ntok + kc8 * 8);
+            if (MASK && ch * KC + kc8 * 8 >= ntok) vreg[it] = u32x4{0u, 0u, 0u, 0u};     // (ntok % 8 == 0: an 8-key piece is whole or absent)
+            else vreg[it] = *reinterpret_cast<const u32x4*>(vbase + (size_t)c * ntok + kc8 * 8);
         }
     };
     stage_k(0, Kbase);
@@ -135,6 +141,13 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
             }
         }
 
+        if (MASK && (ch + 1) * KC > ntok) {            // partial last chunk: keys past the end never win the max and weigh exp2(-huge) = 0
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ch * KC + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= ntok) st[t][r] = -3.0e38f;
+        }
         // ---- softmax statistics for this lane's query (shared with lane ^ 32)
         float mx = st[0][0];
 #pragma unroll
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void attn_kernel(const bf16* __restrict__ 
             const auto s1 = __builtin_amdgcn_permlane32_swap(x.u[1], y.u[1], false, false);
             u32x4 w;
             w[0] = s0[0]; w[1] = s1[0]; w[2] = s0[1]; w[3] = s1[1];
-            *reinterpret_cast<u32x4*>(op + ct * 32 + pr * 16) = w;
+            if (!MASK || q0 + l31 < ntok) *reinterpret_cast<u32x4*>(op + ct * 32 + pr * 16) = w;
         }
 }
 
@@ -782,6 +795,18 @@ void launch_kt(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, i
     hipLaunchKernelGGL((attn_kernel<KT, NW>), grid, block, lds, s, qk, vt, att, ntok, heads * 64, nbuf);
 }
 
+// any token count (multiple of 8): 128-key chunks, 4-wave workgroups of 128 queries, partial last chunk / block masked
+void launch_masked(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
+    constexpr int KT = 4, NW = 4, KC = KT * 32;
+    const int nbuf = ntok > KC ? 2 : 1;
+    const int lds = nbuf * (KC * 128 + 64 * (KC * 2 + 8));
+    static PerDeviceMax attr_lds;
+    if (attr_lds.raise(lds))
+        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<KT, NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    dim3 grid((ntok + NW * 32 - 1) / (NW * 32), heads, batch), block(NW * 64);
+    hipLaunchKernelGGL((attn_kernel<KT, NW, true>), grid, block, lds, s, qk, vt, att, ntok, heads * 64, nbuf);
+}
+
 void launch_attn2(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
     constexpr int lds = 2 * 128 * 128 + 2 * 64 * 256 + 4 * 16 * 144;
     static PerDeviceOnce attr_set;
@@ -802,7 +827,7 @@ void launch_attention(const bf16* qk, const bf16* vt, bf16* att, int batch, int 
     else if (ntok == 128) launch_kt<4, 4>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 64) launch_kt<2, 2>(qk, vt, att, batch, ntok, heads, s);
     else if (ntok == 32) launch_kt<1, 1>(qk, vt, att, batch, ntok, heads, s);
-    // other token counts are rejected in tld_engine_create
+    else launch_masked(qk, vt, att, batch, ntok, heads, s);       // any other multiple of 8 (tld_engine_create checks)
 }
 
 }  // namespace tld

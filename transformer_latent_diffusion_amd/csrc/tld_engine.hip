@@ -460,8 +460,10 @@ int tld_engine_create(const tld_config* c, tld_engine** out) {
     if (c->patch_size <= 0 || c->image_size % c->patch_size != 0)
         return fail(TLD_ERR_INVALID, "image_size=%d must be divisible by patch_size=%d", c->image_size, c->patch_size);
     const int grid = c->image_size / c->patch_size, ntok = grid * grid;
-    if (!(ntok == 32 || ntok == 64 || ntok == 128 || ntok % 256 == 0))
-        return fail(TLD_ERR_INVALID, "token count %d unsupported (need 32, 64, 128 or a multiple of 256)", ntok);
+    // round 4: any grid whose side is a multiple of 4 (token count a multiple of 16: the 16-row groups of the cross-attention row kernel, 16-byte V^T
+    // rows); 64 / 128 / k 256 tokens have shape-specialised attention kernels, everything else takes the masked chunked one
+    if (ntok % 16 != 0)
+        return fail(TLD_ERR_INVALID, "token count %d unsupported: image_size / patch_size must be a multiple of 4", ntok);
     const int pd = c->n_channels * c->patch_size * c->patch_size;
     if (pd > 64) return fail(TLD_ERR_INVALID, "patch_dim=%d > 64 unsupported", pd);
     if (c->noise_embed_dims % 2 || c->noise_embed_dims <= 0) return fail(TLD_ERR_INVALID, "noise_embed_dims must be even");
@@ -1084,8 +1086,8 @@ int tld_debug_dwconv_gelu(const void* in, const float* weight, const float* bias
 int tld_debug_attention_fwd(const void* qk, const void* vt, void* att, int32_t batch, int32_t ntok, int32_t heads, int32_t iters,
                             float* ms_per_launch, void* hip_stream) {
     if (!qk || !vt || !att || batch <= 0 || heads <= 0 || iters <= 0) return fail(TLD_ERR_INVALID, "bad argument");
-    if (!(ntok == 32 || ntok == 64 || ntok == 128 || (ntok > 0 && ntok % 256 == 0)))
-        return fail(TLD_ERR_INVALID, "attention supports 32, 64, 128 or a multiple of 256 tokens (got %d)", ntok);
+    if (ntok <= 0 || ntok % 8 != 0)
+        return fail(TLD_ERR_INVALID, "attention supports token counts that are multiples of 8 (got %d)", ntok);
     PtrDeviceGuard guard(qk);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     hipEvent_t e0 = nullptr, e1 = nullptr;
