@@ -499,7 +499,9 @@ __global__ __launch_bounds__(512) void cross_row_mfma_kernel(CrossRowParams p, i
     const size_t ibase = p.x_in ? (size_t)(b % p.src_batch) * p.ntok : obase;
 
     auto pair_row = [&](int g) { return 16 * (g0 + g) + 2 * wid; };   // this wave's row pair of group g (row inside the sample)
-    // the next row pair's loads are in flight while the current one is processed (a second pair in flight measured 1 us SLOWER: 40.8 vs 39.7)
+    // the next row pair's loads are in flight while the current one is processed (a second pair in flight measured 1 us SLOWER: 40.8 vs 39.7; round 4:
+    // the pairs of the next TWO groups by global -> LDS DMA into per-wave slots, own-vmcnt waits, 151 registers, bitwise the same result: 42.3 vs 37.4 us --
+    // bytes in flight are not what the kernel waits for, the per-group chain of reductions and its two barriers is)
     resid4_t xr[2][NQ];
     bf16x4 ar[2][NQ];
     auto fetch = [&](size_t row, resid4_t (&xv)[NQ], bf16x4 (&av)[NQ]) {
