@@ -159,6 +159,29 @@ def test_c4_sampler_1024px_bf16():
     assert e0 <= FWD_TOL and r <= TRAJ_TOL, (e0, r)
 
 
+@pytest.mark.parametrize("image_size,d", [(24, 256), (40, 128)])
+def test_sampler_on_grids_without_a_specialised_attention_kernel(image_size, d):
+    """A 6-step CFG DPM-Solver++(2M) sample on 12 x 12 / 20 x 20 token grids (masked chunked attention, tiled depthwise kernel, no fused paths) against the
+    C restatement's sampler on the same noise and labels: the trajectory tolerance of the golden runs."""
+    from oracle.oracle import OracleDenoiser
+    from transformer_latent_diffusion_amd import Denoiser, DenoiserConfig, DiffusionGenerator, schedule
+    from transformer_latent_diffusion_amd.weights import synth_state_dict
+    cfg = DenoiserConfig(image_size=image_size, n_channels=4, embed_dim=d, n_layers=2)
+    sd = synth_state_dict(cfg, 71)
+    dev = _dev()
+    model = Denoiser(**asdict(cfg)).to(dev)
+    model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    g = torch.Generator().manual_seed(72)
+    x = torch.randn(3, 4, image_size, image_size, generator=g)
+    label = torch.randn(3, 768, generator=g) * 0.5
+    gen = DiffusionGenerator(model, None, dev, torch.float32)
+    lat = gen.generate_latents(label, n_iter=6, num_imgs=3, class_guidance=4.0, seeds=x, sharp_f=0.0, bright_f=0.0, img_size=image_size)
+    ref = OracleDenoiser(cfg, sd).sample(x.numpy(), label.numpy(), schedule.noise_schedule(6, 1), 4.0, True, 0.0, 0.0)
+    r = rel_rms(lat.cpu().numpy(), ref)
+    print(f"{image_size // 2} x {image_size // 2} tokens, d = {d}: 6-step CFG end latent rel-rms {r:.2e}")
+    assert np.isfinite(lat.cpu().numpy()).all() and r <= TRAJ_TOL, r
+
+
 def test_checkpoint_file_into_engine_512px(tmp_path):
     """SURVEY 8(f2) on the device: a reference-format .pth of a 16x16-token (256 px) 100 M-width model is loaded into a 512 px model
     with load_checkpoint_into (README.md:23 workflow; tld/diffusion.py:148-155), the engine is built from it, and its forward
