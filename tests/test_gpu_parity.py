@@ -339,25 +339,28 @@ _FALLBACK_SNIPPET = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
 from test_gpu_parity import load_golden, _engine, _t, rel_rms
-g = load_golden("g5_100m.npz")
+g = load_golden({fixture!r})
 cfg, sd, m = _engine(g)
 out = m(_t(g["x"]), _t(g["sigma"]), _t(g["label"])).cpu().numpy()
 print("REL", rel_rms(out, g["x0"]))
 """
 
 
-@pytest.mark.parametrize("knobs", [{"TLD_FOLD_LN3": "0"}, {"TLD_FOLD_LN1": "0"}, {"TLD_FUSE_DWCONV": "0", "TLD_SHARE_L0": "0"}])
-def test_fallback_paths_vs_golden(knobs):
+@pytest.mark.parametrize("knobs,fixture", [({"TLD_FOLD_LN3": "0"}, "g5_100m.npz"), ({"TLD_FOLD_LN1": "0"}, "g5_100m.npz"),
+                                           ({"TLD_FUSE_DWCONV": "0", "TLD_SHARE_L0": "0"}, "g5_100m.npz"),
+                                           ({"TLD_FUSE_DWCONV": "0"}, "g7_100m_512px.npz")])
+def test_fallback_paths_vs_golden(knobs, fixture):
     """The engine's structural switches select the paths other SHAPES take by themselves (no LayerNorm folds off the 100 M width, separate
-    depthwise kernel off the 16 x 16 grid; g16 covers those shapes natively): at the 100 M width each must still reproduce the golden
-    forward.  (TLD_FUSE_QKV_ATTN=0 has a test of its own, test_gpu_configs.py.)  The switches are read when an engine is created."""
+    depthwise kernel off the 16 x 16 / 32 x 32 grids; g16 covers those shapes natively): at the 100 M width each must still reproduce the golden
+    forward -- at 512 px too, where the row-streaming depthwise kernel is otherwise only reached in fp8 mode since the 32 x 32 fusion of round 4.
+    (TLD_FUSE_QKV_ATTN=0 has a test of its own, test_gpu_configs.py.)  The switches are read when an engine is created."""
     import os
     import subprocess
     import sys
     tests = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(tests)
     env = dict(os.environ, **knobs)
-    r = subprocess.run([sys.executable, "-c", _FALLBACK_SNIPPET.format(root=root, tests=tests)], env=env,
+    r = subprocess.run([sys.executable, "-c", _FALLBACK_SNIPPET.format(root=root, tests=tests, fixture=fixture)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     rel = float([ln for ln in r.stdout.splitlines() if ln.startswith("REL")][-1].split()[1])

@@ -246,6 +246,8 @@ enum GemmEpilogue {
     EPI_BIAS_BF16 = 2,   // bf16(C + bias[n]) -> [M,N]           (MLP up projection)
     EPI_BIAS_RESID = 3,  // x[m,n] += C + bias[n] (resid_t)      (MLP down projection)
     EPI_QKV_LN = 5,      // EPI_QKV with LayerNorm-1 folded in (A = raw residual stream, see GemmParams::ln_stats)
+    EPI_UP_DWCONV32 = 4, // the same on a 32 x 32 token grid (a tile = 8 image rows): interior rows here, seam rows by launch_dwconv_seam (round 4; a separate
+                         //   instantiation so that the 16 x 16 kernel's register allocation stays what it was)
     EPI_UP_DWCONV2 = 6,  // bf16(C + bias) -> depthwise 3x3 + bias + GELU over the tile's 16x16 image -> [M,N]  (MLP up projection fused with
                          // the depthwise conv: token-pair image in LDS, packed-bf16 taps on v_dot2c_f32_bf16; needs ntok == 256, BN == 256.
                          // Value 4 was the first form of this epilogue, retired in round 4.)
@@ -318,6 +320,9 @@ struct GemmParams {
     int ntok, d;                  // EPI_QKV
     const float* bias;            // EPI_BIAS_*
     const float* dw_b;            // EPI_UP_DWCONV2: HALVED depthwise bias [N]  (the epilogue's GELU takes x / 2)
+    uint32_t* dw_seam;            // EPI_UP_DWCONV32: the epilogue computes the six interior rows of its 8 image rows (+ the image's own top / bottom row) and leaves
+                                  //   rows 0, 1, 6, 7 of the hidden tensor, in its token-pair image format, here for launch_dwconv_seam:
+                                  //   [M / 256 tiles][N / 256 column tiles][64 pair-rows][256 channels] dwords
     const uint32_t* dw_wpk;       // EPI_UP_DWCONV2: HALVED depthwise taps as packed bf16 pairs [3 window rows][4 kinds][N]:
                                   //   kinds (lo, hi): (0, w0), (w1, w2) for even output columns; (w0, w1), (w2, 0) for odd ones
     resid_t* resid; int ldr;      // EPI_BIAS_RESID
@@ -372,6 +377,8 @@ struct GemmParams {
 };
 
 void launch_gemm(const GemmParams& p, int epilogue, hipStream_t s);
+// the two rows on either side of every tile seam of a 32 x 32 image (dw_grid = 32): depthwise 3x3 + GELU on the seam rows the fused epilogue left
+void launch_dwconv_seam(const uint32_t* seam, const uint32_t* dw_wpk, const float* dw_b_half, bf16* out, int ldo, int batch, int channels, hipStream_t s);
 void launch_gemm_tn(const GemmParams& p, hipStream_t s);        // EPI_F32, 256 x 256 tiles: M % 256 == 0, N % 256 == 0, K % 64 == 0, tn_ktotal % 64 == 0
 
 // thread-local message behind tld_last_error() (tld_engine.hip); for the other host translation units

@@ -125,6 +125,7 @@ struct tld_engine {
     bool fold_ln3 = true;              // TLD_FOLD_LN3=0: cross_row writes LN3(x) and the up-projection reads it (A/B testing)
     float2* row_stats = nullptr;       // [M] (mean, rstd) of the residual rows, cross_row -> up-projection epilogue
     bf16 *xn = nullptr, *qk = nullptr, *vt = nullptr, *att = nullptr, *hid1 = nullptr, *hid2 = nullptr;
+    uint32_t* seam = nullptr;            // 32 x 32 grids: the seam rows of the hidden tensor between the fused up-projection and launch_dwconv_seam
     float *io_x = nullptr, *io_sigma = nullptr, *io_label = nullptr, *io_out = nullptr;
     float *xt = nullptr, *x0_prev = nullptr, *x0_cfg = nullptr;
     int* rows_dev = nullptr;           // noise_row / label_row tables
@@ -358,7 +359,9 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
         }
         // 256 px (16x16 tokens): one GEMM tile row-block is one image, so the depthwise conv + GELU run inside the
         // up-projection's epilogue and the pre-conv hidden never reaches HBM.  Other grids: separate kernels.
-        const bool fuse_dw = e->fuse_dwconv && e->grid == 16 && e->hid % 256 == 0;
+        // 512 px (32x32 tokens, round 4): a tile row-block is 8 image rows; the epilogue finishes the interior rows and a thin second kernel the two rows at
+        // every tile seam from the hidden rows the epilogue leaves for it (half of the hidden tensor instead of a write + read of all of it).
+        const bool fuse_dw = e->fuse_dwconv && (e->grid == 16 || (e->grid == 32 && e->seam)) && e->hid % 256 == 0;
         const bool fold3 = e->fold_ln3;                 // LN3 applied in the up-projection's epilogue: cross_row writes row statistics, not xn
         {   // x += att; x += CA(LN2 x, y); xn = LN3(x) (or its row statistics)
             ProfScope ps(e, KC_CROSS, s);
@@ -389,7 +392,12 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
                 g.A = e->x; g.W = Ly.up_wf; g.bias = Ly.up_b1; g.ln_c1 = Ly.up_c1; g.row_stats = e->row_stats;
             }
 #endif
-            launch_gemm(g, EPI_UP_DWCONV2, s);
+            g.dw_seam = e->seam;
+            launch_gemm(g, e->grid == 32 ? EPI_UP_DWCONV32 : EPI_UP_DWCONV2, s);
+            if (e->grid == 32) {
+                ProfScope ps2(e, KC_DWCONV, s);
+                launch_dwconv_seam(e->seam, Ly.dw_wpk, Ly.dw_b_half, e->hid2, e->hid, batch, e->hid, s);
+            }
         } else {
             {   // hid1 = xn Wup^T + b
                 ProfScope ps(e, KC_GEMM_UP, s);
@@ -780,6 +788,7 @@ int tld_engine_finalize_weights(tld_engine* e) {
     if (int rc = dev_alloc(e, &e->vt, M * d)) return rc;
     if (int rc = dev_alloc(e, &e->att, M * d)) return rc;
     if (int rc = dev_alloc(e, &e->hid1, M * hid)) return rc;
+    if (e->grid == 32 && e->fuse_dwconv && hid % 256 == 0) { if (int rc = dev_alloc(e, &e->seam, M * hid / 4)) return rc; }
     if (int rc = dev_alloc(e, &e->hid2, M * hid)) return rc;
     if (e->fp8) {
         if (int rc = dev_alloc(e, &e->a8, M * hid)) return rc;

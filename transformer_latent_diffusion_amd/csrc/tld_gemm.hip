@@ -86,7 +86,7 @@ struct G256P : G256<BN> {
     // of one channel, [128 pairs][256 channels] with a 1-KiB pitch (no padding needed: every access of a wave is a
     // contiguous run), an all-zero pair-row for the rows above / below the image, then the (mean, rstd) pairs
     static constexpr int IMG2_PITCH = 1024, IMG2_BYTES = 128 * IMG2_PITCH;
-    static constexpr int ZROW_OFF = IMG2_BYTES, ZROW_BYTES = 8 * IMG2_PITCH;
+    static constexpr int ZROW_OFF = IMG2_BYTES, ZROW_BYTES = 16 * IMG2_PITCH;          // (16 pair-rows: one row of the 32-wide grid; the 16-wide form reads 8)
     static constexpr int ROWSTAT2_OFF = ZROW_OFF + ZROW_BYTES;
     static constexpr int CB2_OFF = ROWSTAT2_OFF + 256 * 8;          // c1 | bias of the tile's 256 columns (fp32)
     static constexpr int UPDW2_LDS = CB2_OFF + 2048;
@@ -124,6 +124,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     static_assert(!CONV || (!F8 && (EPI == EPI_F32 || EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_RESID)), "conv mode");
     constexpr bool PLAIN_CB = EPI == EPI_BIAS_BF16 && BN != 384 && !F8 && !CONV;       // bias / c1 of the tile's columns staged in LDS (see aux_dma)
     constexpr bool IS_QKV = EPI == EPI_QKV || EPI == EPI_QKV_LN, LN = EPI == EPI_QKV_LN || EPI == EPI_QKV_ATTN;
+    constexpr bool UPDW = EPI == EPI_UP_DWCONV2 || EPI == EPI_UP_DWCONV32;       // fused depthwise epilogues (16 x 16 / 32 x 32 token grids)
     static_assert(EPI != EPI_QKV_ATTN || (BN == 192 && !F8 && !CONV && !RING), "the fused attention epilogue is written for 256 x 192 tiles");
     static_assert(EPI != EPI_QKV_ATTN || G::ATTN_LDS <= 160 * 1024, "LDS");
     static_assert(8 * G::SCRATCH <= G::STAGE_BYTES, "epilogue scratch must fit in one stage");
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         // everywhere except the fp32 debug epilogue.  The V^T tiles of the QKV GEMM are swapped too and transposed on
         // their way through the epilogue scratch with 2-byte LDS writes: one K-loop instantiation instead of two took
         // the kernel from 245 to 213 VGPRs and 111 -> 110 us.
-        constexpr bool swapped = EPI != EPI_F32 && EPI != EPI_UP_DWCONV2;   // (the pair image wants lane = channel)
+        constexpr bool swapped = EPI != EPI_F32 && !UPDW;   // (the pair image wants lane = channel)
         bool v_tile = false;
         if constexpr (IS_QKV) v_tile = n0 >= 2 * p.d;
 
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     }
                 }
             }
-            if constexpr (EPI == EPI_UP_DWCONV2) {
+            if constexpr (UPDW) {
                 constexpr int RS_OFF = G::ROWSTAT2_OFF;
                 if (p.row_stats && wid < 2) {
                     const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 if (k == (nkt > 1 ? 1 : 0)) aux_dma();        // (K = 64: the tile's only K-step; every wave is past the previous epilogue since the barrier above)
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
-                const bool more = (k + 1 < nkt) || (has_next && EPI != EPI_UP_DWCONV2);
+                const bool more = (k + 1 < nkt) || (has_next && !UPDW);
                 const int pkb = (k + 1 < nkt) ? (k + 1) * G::BK * 2 : 0;
                 if constexpr (CONV) {
                     if (k + 1 < nkt) {
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         auto kloop_ring = [&](auto swp) {
             if constexpr (RING) {
             constexpr bool SW = decltype(swp)::value;
-            constexpr bool NOXT = EPI == EPI_UP_DWCONV2;
+            constexpr bool NOXT = UPDW;
             using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
             using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
             const int grp = wid >> 2;
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         } else {
             __builtin_amdgcn_s_barrier();          // all waves finished reading the last stage: reuse it as scratch
             char* ws = RING ? smem + 4 * HT + wid * G::SCRATCH : smem + ((g - 1) & 1) * G::STAGE_BYTES + wid * G::SCRATCH;   // (ring: slots 4-7 are free by now)
-            if constexpr (EPI == EPI_UP_DWCONV2) {
+            if constexpr (UPDW) {
                 // Fused depthwise 3x3 + GELU epilogue (tld/transformer_blocks.py:96-103).  The tile's 256 rows are the 16 x 16 tokens of ONE
                 // sample, so the conv of the MLP is tile-local: the pre-conv hidden tensor never travels to HBM (a 200 MB write + read per
                 // layer) and the separate kernel disappears.  (A first form -- token-major fp32 window, packed FMAs -- was retired in round 4:
@@ -861,7 +862,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 static_assert(BN == 256, "fused depthwise epilogue is written for 256-column tiles");
                 char* H = smem;
                 {   // zero pair-row (never overwritten by the stages: it lies behind them)
-                    if (it == 0) *reinterpret_cast<u32x4*>(smem + G::ZROW_OFF + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};
+                    if (it == 0) {
+                        *reinterpret_cast<u32x4*>(smem + G::ZROW_OFF + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};
+                        *reinterpret_cast<u32x4*>(smem + G::ZROW_OFF + 8192 + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};
+                    }
                 }
                 const bool ln3 = p.row_stats != nullptr;
                 float cst[G::TN], bst[G::TN];
@@ -907,7 +911,99 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     }
                 }
                 __builtin_amdgcn_s_barrier();
-                if (!TLD_EPI_BIT(4)) {
+                if constexpr (EPI == EPI_UP_DWCONV32) {
+                    // ---- 32 x 32 token grid (512 px): the tile is image rows 8 t .. 8 t + 7 of one sample (t = tile row & 3).  Same image format -- token
+                    // pair (row 32 + col) >> 1, 16 pair-columns per row -- and the same tap arithmetic as the 16 x 16 form below.  Output rows 1 .. 6 need
+                    // only tile rows; rows 0 and 7 need the neighbouring tile's hidden rows unless they are the image's own top / bottom row (zero pad).
+                    // Work items: (row pair r0 in {1, 3, 5}) x (column half) = 6 of the 8 thread groups; groups 6, 7 do the image-border row of the first /
+                    // last tile of a sample.  The tile's rows 0, 1, 6, 7 go to p.dw_seam as they stand in the image; launch_dwconv_seam finishes the
+                    // two rows at every seam from them.
+                    const int cq = threadIdx.x & 63;
+                    const int c0 = n0 + cq * 4;
+                    const int w2 = threadIdx.x >> 6;
+                    const int trow = (m0 >> 8) & 3;                       // which quarter of the sample
+                    {   // seam rows: pair-rows [0, 32) and [96, 128) of the image, 16 bytes (4 channels) per thread and pair-row
+                        uint32_t* sb = p.dw_seam + ((size_t)(m0 >> 8) * (p.N >> 8) + (n0 >> 8)) * (64 * 256);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int pr = w2 * 8 + k;                                         // 0 .. 63
+                            const int src = pr < 32 ? pr : pr + 64;
+                            if (pr < 32 ? trow == 0 : trow == 3) continue;                     // (no seam above the sample's first tile / below its last)
+                            *reinterpret_cast<u32x4*>(sb + (size_t)pr * 256 + cq * 4) = *reinterpret_cast<const u32x4*>(H + src * G::IMG2_PITCH + cq * 16);
+                        }
+                    }
+                    // work split: wave group w2 owns pair-columns 2 w2 and 2 w2 + 1 (token columns 4 w2 .. 4 w2 + 3) of EVERY row pair -- (1, 2), (3, 4), (5, 6), and in
+                    // the first / last tile of a sample also (0, 1) / (6, 7), of which only the image-border row is stored.  (A first version gave six of the
+                    // eight groups a (row pair, column half) each and left two idle on interior tiles: 235 us per launch against 165 + 94 for the two kernels.)
+                    {
+                        u32x4 WA[3], WB[3], WC[3], WD[3];
+#pragma unroll
+                        for (int du = 0; du < 3; ++du) {
+                            WA[du] = *reinterpret_cast<const u32x4*>(p.dw_wpk + (size_t)(du * 4 + 0) * p.N + c0);
+                            WB[du] = *reinterpret_cast<const u32x4*>(p.dw_wpk + (size_t)(du * 4 + 1) * p.N + c0);
+                            WC[du] = *reinterpret_cast<const u32x4*>(p.dw_wpk + (size_t)(du * 4 + 2) * p.N + c0);
+                            WD[du] = *reinterpret_cast<const u32x4*>(p.dw_wpk + (size_t)(du * 4 + 3) * p.N + c0);
+                        }
+                        const float4 bsv = *reinterpret_cast<const float4*>(p.dw_b + c0);
+                        const f32x4 bs = {bsv.x, bsv.y, bsv.z, bsv.w};
+                        auto dot2 = [](unsigned a, unsigned b, float c) {
+                            return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b), c, false);
+                        };
+                        const int npairs = (trow == 0 || trow == 3) ? 4 : 3;
+#pragma unroll 1
+                        for (int pi = 0; pi < npairs; ++pi) {
+                            const int r0 = pi < 3 ? 1 + 2 * pi : (trow == 0 ? 0 : 6);
+                            const bool st0 = pi < 3 || trow == 0, st1 = pi < 3 || trow == 3;
+                            const char* rb[4];                                   // window rows r0 - 1 .. r0 + 2 (16 pair-columns each)
+#pragma unroll
+                            for (int k4 = 0; k4 < 4; ++k4) {
+                                const int rr = r0 - 1 + k4;
+                                rb[k4] = ((rr < 0 || rr > 7) ? smem + G::ZROW_OFF : H + rr * 16 * G::IMG2_PITCH) + cq * 16;
+                            }
+                            auto ld = [&](int q, u32x4 (&c)[4]) {
+#pragma unroll
+                                for (int k4 = 0; k4 < 4; ++k4) c[k4] = *reinterpret_cast<const u32x4*>(rb[k4] + q * G::IMG2_PITCH);
+                            };
+                            auto zero = [&](u32x4 (&c)[4]) {
+#pragma unroll
+                                for (int k4 = 0; k4 < 4; ++k4) c[k4] = u32x4{0u, 0u, 0u, 0u};
+                            };
+                            bf16* dst0 = p.out_bf16 + ((size_t)m0 + (size_t)r0 * 32) * p.ldo + c0;
+                            auto emit = [&](const u32x4 (&L)[4], const u32x4 (&Mc)[4], const u32x4 (&R)[4], int q) {       // q: pair-column inside the row
+#pragma unroll
+                                for (int rr = 0; rr < 2; ++rr) {
+                                    f32x4 ae = bs, ao = bs;
+#pragma unroll
+                                    for (int du = 0; du < 3; ++du)
+#pragma unroll
+                                        for (int ch = 0; ch < 4; ++ch) {
+                                            ae[ch] = dot2(L[rr + du][ch], WA[du][ch], ae[ch]);
+                                            ao[ch] = dot2(Mc[rr + du][ch], WC[du][ch], ao[ch]);
+                                            ae[ch] = dot2(Mc[rr + du][ch], WB[du][ch], ae[ch]);
+                                            ao[ch] = dot2(R[rr + du][ch], WD[du][ch], ao[ch]);
+                                        }
+                                    f32x2 e0 = {ae[0], ae[1]}, e1 = {ae[2], ae[3]}, o0 = {ao[0], ao[1]}, o1 = {ao[2], ao[3]};
+                                    e0 = gelu_erf_fast2_half(e0); e1 = gelu_erf_fast2_half(e1);
+                                    o0 = gelu_erf_fast2_half(o0); o1 = gelu_erf_fast2_half(o1);
+                                    bf16x4 oe, oo;
+                                    oe[0] = (bf16)e0[0]; oe[1] = (bf16)e0[1]; oe[2] = (bf16)e1[0]; oe[3] = (bf16)e1[1];
+                                    oo[0] = (bf16)o0[0]; oo[1] = (bf16)o0[1]; oo[2] = (bf16)o1[0]; oo[3] = (bf16)o1[1];
+                                    if (rr == 0 ? st0 : st1) {
+                                        TLD_STORE(reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 32 + 2 * q) * p.ldo), oe);
+                                        TLD_STORE(reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 32 + 2 * q + 1) * p.ldo), oo);
+                                    }
+                                }
+                            };
+                            u32x4 cL[4], cA[4], cB[4], cR[4];
+                            const int q0 = 2 * w2;
+                            if (w2) ld(q0 - 1, cL); else zero(cL);
+                            ld(q0, cA); ld(q0 + 1, cB);
+                            if (w2 < 7) ld(q0 + 2, cR); else zero(cR);
+                            emit(cL, cA, cB, q0);
+                            emit(cA, cB, cR, q0 + 1);
+                        }
+                    }
+                } else if (!TLD_EPI_BIT(4)) {
                     // (round 4, both measured and dropped: these 13 loads hoisted above the image write -- 20 spilled registers, 188 -> 198 us -- and the
                     // same constants staged in LDS by DMA with the side tables -- neutral, 185.5 vs 185.4 us: their latency is not what this phase waits for)
                     const int cq = threadIdx.x & 63;                     // channel quad
@@ -1383,7 +1479,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     GemmParams pg = p;
     static const bool half_tail = !(getenv("TLD_GEMM_HALFTAIL") && atoi(getenv("TLD_GEMM_HALFTAIL")) == 0);     // test hook: tests/test_gpu_parity.py holds the row-split tail bitwise equal to the unsplit run
     pg.half_tail = half_tail ? 1 : 0;
-    if ((epilogue == EPI_UP_DWCONV2 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
+    if ((epilogue == EPI_UP_DWCONV2 || epilogue == EPI_UP_DWCONV32 || epilogue == EPI_BIAS_BF16) && ntn % 2 == 0 && ntm >= 8 && nblocks == ncu && ncu % 8 == 0)
         pg.xcd_ngroups = 2;
     // (EPI_QKV_ATTN, round 4: its PMC traffic is 2.6 x algorithmic -- an XCD's round of 32 items wants 2.7 samples' A tiles + all 12 heads' weights,
     // 4.6 MB against 4 MB of L2 -- but two or four head groups over the XCDs left the kernel at 131.7 us: like the other GEMMs it is not fetch-bound)
@@ -1399,7 +1495,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
 #define TLD_L256P__(E, F8, CV)                                                                        \
     do {                                                                                              \
         constexpr int lds = (F8) ? G::LDS_BYTES + 4096                                                \
-                            : ((E) == EPI_UP_DWCONV2 ? G::UPDW2_LDS                                   \
+                            : (((E) == EPI_UP_DWCONV2 || (E) == EPI_UP_DWCONV32) ? G::UPDW2_LDS                                   \
                             : ((E) == EPI_QKV_ATTN ? G::ATTN_LDS                                      \
                             : ((E) == EPI_QKV_LN ? G::QKVLN_LDS                                        \
                             : ((E) == EPI_BIAS_BF16 && BN != 384 ? G::PLAINLN_LDS : G::LDS_BYTES))));  /* (384-wide: 160 KB of stages, no LayerNorm-3 fold) */ \
@@ -1444,6 +1540,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
             case EPI_BIAS_BF16: TLD_L256P(EPI_BIAS_BF16); break;
             case EPI_BIAS_RESID: TLD_L256P(EPI_BIAS_RESID); break;
             case EPI_UP_DWCONV2: if constexpr (BN == 256) { TLD_L256P(EPI_UP_DWCONV2); } break;
+            case EPI_UP_DWCONV32: if constexpr (BN == 256) { TLD_L256P(EPI_UP_DWCONV32); } break;
             default: break;
         }
     }
@@ -1471,7 +1568,7 @@ int choose_bn(long M, long N, int epilogue) {
     // tiles, which is what the LayerNorm-1 partial sums are defined on (results must not depend on the batch size)
     if (epilogue == EPI_BIAS_RESID && N % 192 == 0) bn = 192;
     if (epilogue == EPI_BIAS_RESID && N % 384 == 0 && (ntm * (N / 384)) % 256 == 0) bn = 384;
-    if (epilogue == EPI_UP_DWCONV2) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
+    if (epilogue == EPI_UP_DWCONV2 || epilogue == EPI_UP_DWCONV32) bn = 256;          // caller guarantees N % 256 == 0 and one 16x16 image per 256 rows
     if (epilogue == EPI_QKV_ATTN) return 192;       // one tile = one (sample, head): caller guarantees N = heads x 192, ntok == 256
     if (bn == 192 && (epilogue != EPI_BIAS_RESID || N % 192)) bn = 128;
     // N = 768 with the plain bias epilogue (the training step's five per layer): one round of 256 x 384 tiles at the training batch instead of

@@ -1500,6 +1500,81 @@ __global__ __launch_bounds__(320, 4) void dwconv_gelu_stream_kernel(const bf16* 
     if (y < g) { step(R1, R2, R0, y); }
 }
 
+// ---- seam rows of the depthwise conv fused into the up-projection at 32 x 32 tokens (GemmParams::dw_grid = 32, tld_gemm.hip) ----------------------
+// A 256-row GEMM tile is 8 rows of the image; its epilogue finishes rows 1 .. 6 (and the image's own border rows) and leaves its hidden rows 0, 1, 6, 7
+// in `seam` as token-pair dwords: [tile][column tile][64 pair-rows: rows 0, 1, 6, 7 x 16 pair-columns][256 channels].  Here: the output rows on either
+// side of each of a sample's three tile seams -- window rows (6, 7) of the upper tile and (0, 1) of the lower one -- with the epilogue's own tap
+// arithmetic (halved taps as packed bf16 pairs, v_dot2 accumulation in fp32, GELU of twice the argument).  One workgroup per (sample, seam, column
+// tile): 64 channel quads x 4 column quarters.
+__global__ __launch_bounds__(256) void dwconv_seam_kernel(const uint32_t* __restrict__ seam, const uint32_t* __restrict__ wpk, const float* __restrict__ bias_half,
+                                                          bf16* __restrict__ out, int ldo, int channels) {
+    const int ntn = channels >> 8;
+    int bid = blockIdx.x;
+    const int n = bid % ntn; bid /= ntn;
+    const int sm = bid % 3, b = bid / 3;
+    const int cq = threadIdx.x & 63, qq = threadIdx.x >> 6;
+    const int c0 = n * 256 + cq * 4;
+    const uint32_t* lo = seam + ((size_t)(b * 4 + sm) * ntn + n) * (64 * 256) + cq * 4;        // upper tile: its rows 6, 7 are pair-rows 32 .. 63
+    const uint32_t* hi = seam + ((size_t)(b * 4 + sm + 1) * ntn + n) * (64 * 256) + cq * 4;    // lower tile: its rows 0, 1 are pair-rows 0 .. 31
+    u32x4 WA[3], WB[3], WC[3], WD[3];
+#pragma unroll
+    for (int du = 0; du < 3; ++du) {
+        WA[du] = *reinterpret_cast<const u32x4*>(wpk + (size_t)(du * 4 + 0) * channels + c0);
+        WB[du] = *reinterpret_cast<const u32x4*>(wpk + (size_t)(du * 4 + 1) * channels + c0);
+        WC[du] = *reinterpret_cast<const u32x4*>(wpk + (size_t)(du * 4 + 2) * channels + c0);
+        WD[du] = *reinterpret_cast<const u32x4*>(wpk + (size_t)(du * 4 + 3) * channels + c0);
+    }
+    const float4 bsv = *reinterpret_cast<const float4*>(bias_half + c0);
+    const f32x4 bs = {bsv.x, bsv.y, bsv.z, bsv.w};
+    // the six pair-columns 4 qq - 1 .. 4 qq + 4 of the four window rows (zero outside the image)
+    u32x4 w[6][4];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int q = 4 * qq - 1 + k;
+        const bool ok = q >= 0 && q < 16;
+        const int qc = ok ? q : 0;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        w[k][0] = ok ? *reinterpret_cast<const u32x4*>(lo + (size_t)(32 + qc) * 256) : z;
+        w[k][1] = ok ? *reinterpret_cast<const u32x4*>(lo + (size_t)(48 + qc) * 256) : z;
+        w[k][2] = ok ? *reinterpret_cast<const u32x4*>(hi + (size_t)qc * 256) : z;
+        w[k][3] = ok ? *reinterpret_cast<const u32x4*>(hi + (size_t)(16 + qc) * 256) : z;
+    }
+    auto dot2 = [](unsigned a, unsigned b2, float c) {
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, a), __builtin_bit_cast(bf16x2, b2), c, false);
+    };
+    bf16* dst0 = out + ((size_t)b * 1024 + (size_t)(8 * sm + 7) * 32) * ldo + c0;             // image row 8 sm + 7; the next row is 32 tokens on
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const u32x4 (&L)[4] = w[k]; const u32x4 (&Mc)[4] = w[k + 1]; const u32x4 (&R)[4] = w[k + 2];
+        const int q = 4 * qq + k;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            f32x4 ae = bs, ao = bs;
+#pragma unroll
+            for (int du = 0; du < 3; ++du)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    ae[ch] = dot2(L[rr + du][ch], WA[du][ch], ae[ch]);
+                    ao[ch] = dot2(Mc[rr + du][ch], WC[du][ch], ao[ch]);
+                    ae[ch] = dot2(Mc[rr + du][ch], WB[du][ch], ae[ch]);
+                    ao[ch] = dot2(R[rr + du][ch], WD[du][ch], ao[ch]);
+                }
+            f32x2 e0 = {ae[0], ae[1]}, e1 = {ae[2], ae[3]}, o0 = {ao[0], ao[1]}, o1 = {ao[2], ao[3]};
+            e0 = gelu_erf_fast2_half(e0); e1 = gelu_erf_fast2_half(e1);
+            o0 = gelu_erf_fast2_half(o0); o1 = gelu_erf_fast2_half(o1);
+            bf16x4 oe, oo;
+            oe[0] = (bf16)e0[0]; oe[1] = (bf16)e0[1]; oe[2] = (bf16)e1[0]; oe[3] = (bf16)e1[1];
+            oo[0] = (bf16)o0[0]; oo[1] = (bf16)o0[1]; oo[2] = (bf16)o1[0]; oo[3] = (bf16)o1[1];
+            *reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 32 + 2 * q) * ldo) = oe;
+            *reinterpret_cast<bf16x4*>(dst0 + ((size_t)rr * 32 + 2 * q + 1) * ldo) = oo;
+        }
+    }
+}
+
+void launch_dwconv_seam(const uint32_t* seam, const uint32_t* dw_wpk, const float* dw_b_half, bf16* out, int ldo, int batch, int channels, hipStream_t s) {
+    hipLaunchKernelGGL(dwconv_seam_kernel, dim3((unsigned)(batch * 3 * (channels >> 8))), dim3(256), 0, s, seam, dw_wpk, dw_b_half, out, ldo, channels);
+}
+
 void launch_dwconv_gelu(const bf16* in, bf16* out, const float* w9c, const float* bias, const float* w9c_half,
                         const float* bias_half, int batch, int grid, int channels, hipStream_t s, uint8_t* out8,
                         uint8_t* scale8) {
