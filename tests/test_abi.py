@@ -41,7 +41,7 @@ def test_engine_create_without_gpu_reports_error():
 def test_engine_create_rejects_bad_configs():
     L = _lib.lib()
     h = C.c_void_p()
-    for bad in (dict(embed_dim=100), dict(embed_dim=0), dict(image_size=33), dict(max_batch=0), dict(image_size=8)):
+    for bad in (dict(embed_dim=100), dict(embed_dim=0), dict(image_size=33), dict(max_batch=0), dict(image_size=12)):       # 6 x 6 tokens: the grid side must be a multiple of 4
         kw = dict(image_size=32, noise_embed_dims=256, patch_size=2, embed_dim=128, n_layers=3, text_emb_size=768,
                   n_channels=4, mlp_multiplier=4, max_batch=8, device_id=0)
         kw.update(bad)
