@@ -29,11 +29,12 @@ typedef struct tld_engine tld_engine;
 /* Mirrors tld/configs.py:21-31 DenoiserConfig (dropout is identity at inference and not carried),
  * plus engine sizing.  Replaces the kwargs of Denoiser.__init__ (tld/denoiser.py:86-97). */
 typedef struct tld_config {
-    int32_t image_size;
-    int32_t noise_embed_dims;
-    int32_t patch_size;
+    int32_t image_size;       /* image_size / patch_size (the token grid's side) must be a multiple of 4; the reference takes any square
+                                 grid (tld/transformer_blocks.py:109) -- tld_engine_create says so when it refuses one */
+    int32_t noise_embed_dims; /* even */
+    int32_t patch_size;       /* n_channels * patch_size^2 (the patch vector) <= 64 */
     int32_t embed_dim;        /* any multiple of the head width 64 up to 1024: heads = embed_dim / 64 (tld/transformer_blocks.py:126-128);
-                                 the training engine (tld_train_*) takes multiples of 128 */
+                                 the training engine (tld_train_*) takes the same widths */
     int32_t n_layers;
     int32_t text_emb_size;
     int32_t n_channels;

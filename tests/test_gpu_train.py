@@ -311,7 +311,41 @@ if w > 1:
     tr2.optimizer_step()
     torch.cuda.synchronize()
     assert torch.equal(tr.params, tr2.params), float((tr.params - tr2.params).abs().max())
-torch.save(tr.params.cpu(), {out!r} + f".{{w}}.{{r}}")
+    # a second forward_backward without an optimizer step in between drains the first call's reductions before the backward rewrites the
+    # gradients, and grad_dict() hands out the fully reduced SUM
+    tr.forward_backward(xn[sl], nl[sl], y[sl], x[sl])
+    tr.forward_backward(xn[sl], nl[sl], y[sl], x[sl])
+    gsum = torch.cat([v.reshape(-1) for v in tr.grad_dict().values()]).clone()
+    assert not tr._pending
+    tr2.forward_backward(xn[sl], nl[sl], y[sl], x[sl]); dist.all_reduce(tr2.grads)
+    torch.cuda.synchronize()
+    assert torch.equal(gsum, tr2.grads)
+    tr.optimizer_step()
+    # an exception inside the gradient-ready callback (ctypes would swallow it) surfaces from forward_backward, on every rank alike, and the
+    # optimizer then refuses nothing silently: the next optimizer_step falls back to the blocking all-reduce of the whole vector
+    real, calls = dist.all_reduce, [0]
+    def flaky(*a, **k):
+        calls[0] += 1
+        if calls[0] == 3:
+            raise RuntimeError("injected collective failure")
+        return real(*a, **k)
+    dist.all_reduce = flaky
+    try:
+        tr.forward_backward(xn[sl], nl[sl], y[sl], x[sl])
+        raise SystemExit("the injected failure did not surface")
+    except RuntimeError as e:
+        assert "all-reduce of a slice failed" in str(e) and "injected" in str(e.__cause__), e
+    finally:
+        dist.all_reduce = real
+    assert not tr._pending and not tr._reduced and len(tr._slices) == 2
+    # partly recorded slices never reach the 1 / world path
+    tr._reduced = True
+    try:
+        tr.optimizer_step()
+        raise SystemExit("stepped on partly reduced gradients")
+    except RuntimeError as e:
+        assert "partly reduced" in str(e), e
+torch.save(tr.params.cpu() if w == 1 else tr2.params.cpu(), {out!r} + f".{{w}}.{{r}}")
 print("rank", r, "done")
 """
 
@@ -429,7 +463,14 @@ def test_checkpoint_is_reference_format_and_resumes(tmp_path):
     g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
     l1 = tr.train_step(x, y, np_rng=np.random.default_rng(8), generator=g1)
     l2 = tr2.train_step(x, y, np_rng=np.random.default_rng(8), generator=g2)
-    assert float(l1) == float(l2) and torch.equal(tr.params, tr2.params) and tr2.step == 4
+    assert float(l1) == float(l2) and torch.equal(tr.params, tr2.params) and tr2.step == 4 and tr2.global_step == 4
+    # a checkpoint without optimizer state (saved before the first step of a run that had itself resumed): the loop counter comes back, Adam's
+    # bias-correction count stays 0 with its zero moments -- torch.optim.Adam does the same with an empty state
+    tr3 = Trainer(cfg, TrainConfig(batch_size=4), device="cuda:0", init_seed=99, max_batch=4)
+    tr3.load_checkpoint({"model_ema": ck["model_ema"], "opt_state": {"state": {}, "param_groups": ck["opt_state"]["param_groups"]}, "global_step": 1000})
+    assert tr3.step == 0 and tr3.global_step == 1000 and tr3.checkpoint()["global_step"] == 1000
+    tr3.optimizer_step()
+    assert tr3.step == 1 and tr3.global_step == 1001
 
 
 def test_trainer_refuses_dropout_and_resolves_current_device():

@@ -25,7 +25,7 @@ import unicodedata
 from functools import lru_cache
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 
-import regex as re
+import re as _stdre
 import torch
 
 SOT, EOT = "<|startoftext|>", "<|endoftext|>"
@@ -77,7 +77,7 @@ def _clean(text: str) -> str:
     except ImportError:                      # not in this image: the NFC step alone, which is also what HuggingFace's normaliser does
         text = unicodedata.normalize("NFC", text)
     text = html.unescape(html.unescape(text)).strip()
-    return re.sub(r"\s+", " ", text).strip()
+    return _stdre.sub(r"\s+", " ", text).strip()
 
 
 class ClipTokenizer:
@@ -89,7 +89,12 @@ class ClipTokenizer:
         self.decoder = {i: t for t, i in self.encoder.items()}
         self.rank = {m: i for i, m in enumerate(self.merges)}
         self._byte = bytes_to_unicode()
-        self._pat = re.compile(_PATTERN, re.IGNORECASE)
+        try:                     # CLIP's pattern uses \p{L} / \p{N}: the third-party ``regex`` module, needed by tokeniser users only
+            import regex
+        except ImportError as e:  # pragma: no cover -- present in this image
+            raise ImportError("ClipTokenizer needs the 'regex' package (unicode property classes in CLIP's split pattern); "
+                              "pip install regex.  Inference from text embeddings and training do not need it.") from e
+        self._pat = regex.compile(_PATTERN, regex.IGNORECASE)
         self._cache: Dict[str, Tuple[str, ...]] = {SOT: (SOT,), EOT: (EOT,)}
         self.sot, self.eot = self.encoder[SOT], self.encoder[EOT]
 

@@ -775,9 +775,8 @@ void launch_attn1(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok
     constexpr int KC = KT * 32;
     const int lds = KC * 128 + 64 * (KC * 2 + 8) + (TLD_ATTN_ST16 == 2 ? NW * 16 * 144 : 0);
     static PerDeviceOnce attr_set;
-    if (attr_set.first())
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn1_kernel<KT, NW, QT, PIPE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(attn1_kernel<KT, NW, QT, PIPE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     hipLaunchKernelGGL((attn1_kernel<KT, NW, QT, PIPE>), dim3(1, heads, batch), dim3(NW * 64), lds, s, qk, vt, att, ntok,
                        heads * 64);
 }
@@ -788,9 +787,8 @@ void launch_kt(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, i
     const int nbuf = (ntok > KC && 2 * (KC * 128 + 64 * (KC * 2 + 8)) <= 160 * 1024) ? 2 : 1;       // (the engine's shapes are all single-chunk here: ntok == KC)
     const int lds = nbuf * (KC * 128 + 64 * (KC * 2 + 8));
     static PerDeviceMax attr_lds;
-    if (attr_lds.raise(lds))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<KT, NW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_lds.run(lds, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<KT, NW>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     dim3 grid(ntok / (NW * 32), heads, batch), block(NW * 64);
     hipLaunchKernelGGL((attn_kernel<KT, NW>), grid, block, lds, s, qk, vt, att, ntok, heads * 64, nbuf);
 }
@@ -801,8 +799,7 @@ void launch_masked(const bf16* qk, const bf16* vt, bf16* att, int batch, int nto
     const int nbuf = ntok > KC ? 2 : 1;
     const int lds = nbuf * (KC * 128 + 64 * (KC * 2 + 8));
     static PerDeviceMax attr_lds;
-    if (attr_lds.raise(lds))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<KT, NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_lds.run(lds, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(attn_kernel<KT, NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     dim3 grid((ntok + NW * 32 - 1) / (NW * 32), heads, batch), block(NW * 64);
     hipLaunchKernelGGL((attn_kernel<KT, NW, true>), grid, block, lds, s, qk, vt, att, ntok, heads * 64, nbuf);
 }
@@ -810,8 +807,7 @@ void launch_masked(const bf16* qk, const bf16* vt, bf16* att, int batch, int nto
 void launch_attn2(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok, int heads, hipStream_t s) {
     constexpr int lds = 2 * 128 * 128 + 2 * 64 * 256 + 4 * 16 * 144;
     static PerDeviceOnce attr_set;
-    if (attr_set.first())
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     hipLaunchKernelGGL(attn2_kernel, dim3(ntok / 256, heads, batch), dim3(256), lds, s, qk, vt, att, ntok, heads * 64);
 }
 

@@ -370,7 +370,7 @@ int tld_clip_encode_text(tld_clip* c, const int32_t* tokens, const int32_t* eot_
     const dim3 rows((T + 3) / 4);
     const size_t attn_lds = (size_t)(ctx * 64 * 2 + ctx * 65 + 128) * sizeof(float);
     static PerDeviceOnce attr_set;
-    if (attr_set.first()) hipFuncSetAttribute(reinterpret_cast<const void*>(clip_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (64 * 2 + 65) * 4 + 512);
+    attr_set.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(clip_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * (64 * 2 + 65) * 4 + 512); });
     hipLaunchKernelGGL(clip_add_ln_kernel, rows, dim3(256), 0, s, c->x, (const float*)nullptr, (const float*)nullptr, c->blocks[0].ln1_g, c->blocks[0].ln1_b, c->h, T, W);
     for (int l = 0; l < c->L; ++l) {
         const Block& b = c->blocks[l];

@@ -1,6 +1,7 @@
 // tld_common.h -- shared device/host declarations of the gfx950 denoising engine.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 
 namespace tld {
@@ -259,25 +260,30 @@ enum GemmEpilogue {
 
 // Launch-side caches are PER DEVICE: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the current device only, and engines on
 // different devices may live in one process (every ABI entry point runs under a device guard).
+// Host threads may drive different devices (or the same one) for the first time concurrently, so the flags are atomic and a flag is
+// published only AFTER the attribute call it guards has returned: a racing thread either sees the bit (the attribute is set) or sets the
+// attribute itself once more, which is harmless.
 struct PerDeviceOnce {
-    unsigned long long mask = 0;
-    bool first() {                                   // true once per device
+    std::atomic<unsigned long long> mask{0};
+    template <class F> void run(F&& set_attribute) {     // set_attribute() runs (at least) once per device, before any launch that needs it
         int dev = 0;
         (void)hipGetDevice(&dev);
         const unsigned long long bit = 1ull << (dev & 63);
-        if (mask & bit) return false;
-        mask |= bit;
-        return true;
+        if (mask.load(std::memory_order_acquire) & bit) return;
+        set_attribute();
+        mask.fetch_or(bit, std::memory_order_release);
     }
 };
 struct PerDeviceMax {                                // largest value requested so far on the current device
-    int v[64] = {0};
-    bool raise(int want) {
+    std::atomic<int> v[64] = {};
+    template <class F> void run(int want, F&& set_attribute) {
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (v[dev & 63] >= want) return false;
-        v[dev & 63] = want;
-        return true;
+        std::atomic<int>& a = v[dev & 63];
+        int cur = a.load(std::memory_order_acquire);
+        if (cur >= want) return;
+        set_attribute();
+        while (cur < want && !a.compare_exchange_weak(cur, want, std::memory_order_release, std::memory_order_acquire)) {}
     }
 };
 // device that owns a device pointer (debug hooks that take raw pointers and no engine); -1 if unknown

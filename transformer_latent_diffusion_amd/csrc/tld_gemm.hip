@@ -1487,9 +1487,8 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
 #define TLD_L256P_LAUNCH(E, F8, CV, RG)                                                               \
     do {                                                                                              \
         static PerDeviceOnce once;                                                                    \
-        if (once.first())                                                                             \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E, F8, CV, RG>),    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
+        once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<BN, E, F8, CV, RG>), \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds); });      \
         hipLaunchKernelGGL((gemm256p_kernel<BN, E, F8, CV, RG>), grid, block, lds, s, pg, nblocks);   \
     } while (0)
 #define TLD_L256P__(E, F8, CV)                                                                        \
@@ -1617,9 +1616,8 @@ void launch_gemm_tn(const GemmParams& p, hipStream_t s) {
     const int ncu = device_cu_count();
     const int nblocks = ntiles < ncu ? ntiles : ncu;
     static PerDeviceOnce once;
-    if (once.first())
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<256, EPI_F32, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            G::LDS_BYTES);
+    once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(gemm256p_kernel<256, EPI_F32, false, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G::LDS_BYTES); });
     hipLaunchKernelGGL((gemm256p_kernel<256, EPI_F32, false, false, false, true>), dim3(nblocks), dim3(512), G::LDS_BYTES, s, p, nblocks);
 }
 

@@ -1260,8 +1260,8 @@ __global__ __launch_bounds__(256) void dwconv_gelu_tiled_kernel(const bf16* __re
 #define TLD_LDS_OPT_IN(KERNEL, bytes)                                                                \
     do {                                                                                             \
         static PerDeviceMax optin;                                                                   \
-        if ((bytes) > 64 * 1024 && optin.raise(bytes))                                               \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+        if ((bytes) > 64 * 1024)                                                                     \
+            optin.run((bytes), [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); }); \
     } while (0)
 
 void launch_embed(const EmbedParams& p, hipStream_t s) {

@@ -343,7 +343,7 @@ int tld_train_forward_backward_cb(tld_train* e, const float* x_noisy, const floa
     const size_t dw_lds = dwconv_lds_bytes(G);
     {
         static PerDeviceOnce once;
-        if (once.first()) hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     }
     const float inv_numel = 1.0f / (float)((size_t)B * e->C * e->S * e->S);
     // the three small fp32 products on the tiled kernel (see tld_train_kernels.h)

@@ -327,8 +327,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const bf16* __restric
 template <int NW, int MODE, typename TG>
 void launch_one(const bf16* qk, const bf16* vt, const bf16* o, const TG* g, bf16* dqkv, float* stats, int batch, int ntok, int heads, hipStream_t s) {
     static PerDeviceOnce once;
-    if (once.first())
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<NW, MODE, TG>), hipFuncAttributeMaxDynamicSharedMemorySize, Lay<NW>::BYTES);
+    once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<NW, MODE, TG>), hipFuncAttributeMaxDynamicSharedMemorySize, Lay<NW>::BYTES); });
     hipLaunchKernelGGL((attn_bwd_kernel<NW, MODE, TG>), dim3(batch * heads * (ntok / (32 * NW))), dim3(64 * NW), Lay<NW>::BYTES, s, qk, vt, o, g, dqkv, stats, heads,
                        ntok);
 }

@@ -141,6 +141,9 @@ class Trainer:
         self.overlap_allreduce = overlap_allreduce
         self._comm_stream = None
         self._pending = []                # async all-reduce handles of the gradient slices of the step in flight
+        self._reduced = False             # True between an overlapped forward_backward and the optimizer_step that consumes its reduced gradients
+        self._cb_error = None             # first exception raised inside the gradient-ready callback (ctypes would swallow it)
+        self.global_step = 0              # tld/train.py:104,174 -- the loop counter the checkpoint carries; Adam's own count is self.step
         self._slices = []                 # (offset, numel) in the order they became ready (tests)
         self._graph = None
         self._graph_calls = 0
@@ -189,6 +192,9 @@ class Trainer:
         return sd
 
     def grad_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        """Views into the flat gradient vector.  In overlap mode with more than one rank these are the cross-rank SUM (not the mean) once the
+        slice reductions have been waited for, which this does."""
+        self.wait_gradients()
         return self._unflatten(self.grads)
 
     def load_state_dict(self, sd: Mapping[str, torch.Tensor]) -> "Trainer":
@@ -235,7 +241,9 @@ class Trainer:
         if B > self.max_batch:
             raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
         overlap = self.overlap_allreduce and self._world() > 1 and not (self.use_graph and B == self.max_batch)
-        self._pending, self._slices = [], []
+        self.wait_gradients()             # a previous call's slice reductions may still be running on the communication stream: they read / write self.grads
+        self._slices = []
+        self._cb_error = None
         cb = None
         if overlap:
             import torch.distributed as dist
@@ -244,12 +252,17 @@ class Trainer:
             compute = torch.cuda.current_stream(dev)
 
             def ready(_user, off, n):      # called by the engine, on this thread, right after the kernels finishing grads[off : off + n] are enqueued
-                ev = torch.cuda.Event()
-                ev.record(compute)
-                self._comm_stream.wait_event(ev)
-                with torch.cuda.stream(self._comm_stream):
-                    self._pending.append(dist.all_reduce(self.grads[off:off + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                self._slices.append((int(off), int(n)))
+                if self._cb_error is not None:
+                    return                 # a slice already failed: the step is void, launch nothing more
+                try:                       # ctypes swallows what a callback raises: keep it and re-raise when the engine call returns
+                    ev = torch.cuda.Event()
+                    ev.record(compute)
+                    self._comm_stream.wait_event(ev)
+                    with torch.cuda.stream(self._comm_stream):
+                        self._pending.append(dist.all_reduce(self.grads[off:off + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self._slices.append((int(off), int(n)))
+                except BaseException as e:  # noqa: BLE001 -- re-raised below
+                    self._cb_error = e
             cb = _lib.GRAD_READY_FN(ready)
 
         def launch(xn_, nl_, lab_, tgt_, pred_, refresh=False):
@@ -259,6 +272,11 @@ class Trainer:
                     _lib.check(_lib.lib().tld_train_forward_backward_cb(self._h, C.c_void_p(xn_.data_ptr()), C.c_void_p(nl_.data_ptr()), C.c_void_p(lab_.data_ptr()),
                                                                         C.c_void_p(tgt_.data_ptr()), B, C.c_void_p(self._loss.data_ptr()), C.c_void_p(pred_.data_ptr()),
                                                                         C.c_void_p(stream), cb, None), "tld_train_forward_backward_cb")
+                    if self._cb_error is not None:
+                        err, self._cb_error = self._cb_error, None
+                        self._abandon_pending()
+                        raise RuntimeError("gradient all-reduce of a slice failed during the backward; the step's gradients are not reduced") from err
+                    self._reduced = True
                     return
                 if refresh:     # graph capture: the bf16 / transposed operand copies are rebuilt INSIDE the captured region, whatever the engine's
                     # weights_fresh flag says at capture time -- every replay then follows the optimizer's latest parameters
@@ -291,17 +309,46 @@ class Trainer:
         import torch.distributed as dist
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
+    def wait_gradients(self) -> None:
+        """Make the current stream wait for every gradient-slice all-reduce still in flight (overlap mode).  Until then ``self.grads`` is a mix of
+        local and summed slices; after it, it is the cross-rank SUM (the optimizer kernel applies 1 / world).  Called by ``grad_dict``,
+        ``optimizer_step`` and at the start of the next ``forward_backward``; a no-op when nothing is pending."""
+        pending, self._pending = self._pending, []
+        for w in pending:
+            w.wait()
+
+    def _abandon_pending(self) -> None:
+        pending, self._pending = self._pending, []
+        for w in pending:
+            try:
+                w.wait()
+            except Exception:      # noqa: BLE001 -- the step is already being abandoned with the first error
+                pass
+        self._reduced = False
+
+    def _slices_tile_vector(self) -> bool:
+        """True when the recorded slices cover [0, numel) exactly once (they arrive last block first; order does not matter here)."""
+        pos = 0
+        for off, n in sorted(self._slices):
+            if off != pos:
+                return False
+            pos += n
+        return pos == self.numel
+
     def optimizer_step(self) -> None:
         """DDP gradient mean + Adam + EMA (tld/train.py:168-172).  The gradient sum over the ranks is either already in flight (per-block slices
         started during the backward, ``overlap_allreduce``) or one all-reduce of the flat vector here."""
-        if self._pending:
-            for w in self._pending:
-                w.wait()                  # the current stream waits for the slice's reduction
-            self._pending = []
+        if self._reduced:
+            self._reduced = False
+            self.wait_gradients()         # the current stream waits for the slices' reductions
+            if not self._slices_tile_vector():
+                raise RuntimeError(f"overlapped gradient all-reduce covered {sum(n for _, n in self._slices)} of {self.numel} elements: "
+                                   "refusing to step on partly reduced gradients")
             scale = 1.0 / self._world()
         else:
             scale = allreduce_mean_(self.grads, self.group)
         self.step += 1
+        self.global_step += 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         p = lambda a: C.c_void_p(a.data_ptr()) if a is not None else None
         with torch.cuda.device(self.device):
@@ -360,10 +407,6 @@ class Trainer:
         """The dict the reference saves (tld/train.py:150-156): EMA weights, ``optimizer.state_dict()``, global step."""
         return {"model_ema": self.ema_state_dict(), "opt_state": self.optimizer_state_dict(), "global_step": self.global_step}
 
-    @property
-    def global_step(self) -> int:
-        return self.step
-
     def load_checkpoint(self, ckpt) -> "Trainer":
         """Resume as the reference does with ``from_scratch=False`` (tld/train.py:92-104): the EMA weights go into the live model (and the EMA
         copy restarts from them), the optimizer state and the step count are restored.  ``ckpt``: the dict, or a path to a torch-saved one."""
@@ -372,6 +415,7 @@ class Trainer:
         sd = {k.replace("_orig_mod.", "").replace("module.", ""): v for k, v in ckpt["model_ema"].items()}
         self.load_state_dict(sd)
         self.load_optimizer_state_dict(ckpt["opt_state"])
-        if "global_step" in ckpt and int(ckpt["global_step"]) != self.step and self.step == 0:
-            self.step = int(ckpt["global_step"])
+        # the loop counter and Adam's bias-correction count are different things: a checkpoint saved before the first optimizer step of a
+        # resumed run (empty Adam state) keeps Adam at step 0 -- fresh moments with step = global_step would be under-corrected
+        self.global_step = int(ckpt.get("global_step", self.step))
         return self
