@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from conftest import cfg_from_arr, load_golden, rel_rms, synth_weights
-from test_gpu_parity import FWD_TOL, TRAJ_TOL, _dev, _engine, _t
+from test_gpu_parity import FWD_REG, FWD_TOL, TRAJ_REG, TRAJ_TOL, _dev, _engine, _t, held
 
 pytestmark = pytest.mark.gpu
 
@@ -117,8 +117,7 @@ def test_c1_full_size_sampler_vs_reference_trajectory():
     kw = dict(n_iter=int(g["traj_n_iter"]), class_guidance=float(g["traj_class_guidance"]), img_size=32, sharp_f=0.0, bright_f=0.0)
     full = gen.generate_latents(labels, num_imgs=B, seeds=seeds, **kw)
     assert torch.isfinite(full).all()
-    r = rel_rms(full[:1].cpu().numpy(), g["traj_latent"])
-    assert r <= TRAJ_TOL, r
+    held(rel_rms(full[:1].cpu().numpy(), g["traj_latent"]), TRAJ_TOL, TRAJ_REG, "C1 end latent of the golden sample inside the 64-image batch")
     one = gen.generate_latents(labels[:1], num_imgs=1, seeds=seeds[:1], **kw)
     assert torch.equal(one[0], full[0])
     assert torch.equal(full, gen.generate_latents(labels, num_imgs=B, seeds=seeds, **kw))      # deterministic
@@ -137,9 +136,8 @@ def test_c3_sampler_512px():
     seeds[0], labels[0] = torch.from_numpy(g["traj_seeds"][0]), torch.from_numpy(g["traj_labels"][0])
     kw = dict(n_iter=int(g["traj_n_iter"]), class_guidance=float(g["traj_class_guidance"]), img_size=64, sharp_f=0.0, bright_f=0.0)
     one, tx0, _ = gen.generate_latents(labels[:1], num_imgs=1, seeds=seeds[:1], trace=True, **kw)
-    assert rel_rms(tx0[0].cpu().numpy(), g["traj_x0_first"]) <= FWD_TOL
-    r = rel_rms(one.cpu().numpy(), g["traj_latent"])
-    assert r <= TRAJ_TOL, r
+    held(rel_rms(tx0[0].cpu().numpy(), g["traj_x0_first"]), FWD_TOL, FWD_REG, "C3 first CFG prediction")
+    held(rel_rms(one.cpu().numpy(), g["traj_latent"]), TRAJ_TOL, TRAJ_REG, "C3 35-step end latent")
     full = gen.generate_latents(labels, num_imgs=B, seeds=seeds, **kw)
     assert torch.isfinite(full).all() and torch.equal(full[0], one[0])
 
@@ -156,7 +154,8 @@ def test_c4_sampler_1024px_bf16():
     e0 = rel_rms(tx0[0].cpu().numpy(), g["traj_x0_first"])
     r = rel_rms(one.cpu().numpy(), g["traj_latent"])
     print(f"C4 bf16: first CFG prediction rel-rms {e0:.2e}, 35-step end latent {r:.2e}")
-    assert e0 <= FWD_TOL and r <= TRAJ_TOL, (e0, r)
+    held(e0, FWD_TOL, FWD_REG, "C4 bf16 first CFG prediction")
+    held(r, TRAJ_TOL, TRAJ_REG, "C4 bf16 35-step end latent")
 
 
 @pytest.mark.parametrize("image_size,d", [(24, 256), (40, 128)])
@@ -253,7 +252,8 @@ print("RESULT", rel_rms(out, g["x0"]), rel_rms(lat, g["traj_latent"]), int(np.ar
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
         fwd, traj, rep, bind = r.stdout.split("RESULT")[1].split()[:4]
         outs[flag] = (float(fwd), float(traj))
-        assert float(fwd) <= FWD_TOL and float(traj) <= TRAJ_TOL, (flag, fwd, traj)
+        held(float(fwd), FWD_TOL, FWD_REG, f"g5 forward, TLD_FUSE_QKV_ATTN={flag}")
+        held(float(traj), TRAJ_TOL, TRAJ_REG, f"g5 trajectory, TLD_FUSE_QKV_ATTN={flag}")
         assert int(rep) == 1 and int(bind) == 1, (flag, rep, bind)
         sa[flag] = np.load(dump)
     print("fused / two-kernel (forward, trajectory):", outs)

@@ -19,6 +19,18 @@ pytestmark = pytest.mark.gpu
 
 FWD_TOL = 2e-2
 TRAJ_TOL = 6e-2
+# A second, TIGHTER pair beside the contract bounds (round 5): ~1.5 x the largest error measured on the pinned fixtures (forward 4.5e-3 .. 7.0e-3,
+# multi-step end latents 0.6e-2 .. 1.4e-2; profiles/r0*_parity_report.md).  The contract bounds say "equal to the reference within SURVEY's
+# tolerance"; these say "no worse than this build has been" -- a wrong GELU coefficient or a dropped LayerNorm-fold term that doubles the error
+# stays inside 2e-2 but not inside 1e-2.
+FWD_REG = 1e-2
+TRAJ_REG = 2.5e-2
+
+
+def held(err, contract, regression, what=""):
+    """Assert the contract tolerance (parity) and the tighter regression bound; both messages carry the measured error."""
+    assert np.isfinite(err) and err <= contract, f"parity: {what} rel-rms {err:.3e} exceeds the contract tolerance {contract:.1e}"
+    assert err <= regression, f"regression: {what} rel-rms {err:.3e} is inside the contract tolerance {contract:.1e} but above the regression bound {regression:.1e}"
 
 
 def _dev():
@@ -95,7 +107,7 @@ def test_g1_stages_tiny32():
     for k, tol in (("blk0_sa", 1e-2), ("blk0_ca", 1e-2), ("blk0_mlp", 1e-2), ("tokens_final", FWD_TOL)):
         st = m.read_stage(k, (B, N, d))
         assert rel_rms(st, g[k]) <= tol, (k, rel_rms(st, g[k]))
-    assert rel_rms(out, g["x0"]) <= FWD_TOL, rel_rms(out, g["x0"])
+    held(rel_rms(out, g["x0"]), FWD_TOL, FWD_REG, "g1 forward")
 
 
 @pytest.mark.parametrize("name", ["g3_tiny16_forward.npz", "g4_wide1_forward.npz", "g5_100m.npz",
@@ -105,8 +117,8 @@ def test_forward_vs_golden(name):
     cfg, sd, m = _engine(g)
     out = m(_t(g["x"]), _t(g["sigma"]), _t(g["label"])).cpu().numpy()
     assert out.shape == g["x0"].shape
-    r = rel_rms(out, g["x0"])
-    assert np.isfinite(out).all() and r <= FWD_TOL, r
+    assert np.isfinite(out).all()
+    held(rel_rms(out, g["x0"]), FWD_TOL, FWD_REG, name)
 
 
 def _sweep_tags():
@@ -164,8 +176,7 @@ def test_g2_sampler_vs_golden(tag, plus):
     for i in range(n - 1):
         assert rel_rms(tx0[i], g[f"{tag}_x0"][i]) <= TRAJ_TOL, ("x0", i, rel_rms(tx0[i], g[f"{tag}_x0"][i]))
         assert rel_rms(txt[i], g[f"{tag}_xt"][i + 1]) <= TRAJ_TOL, ("xt", i)
-    r = rel_rms(lat.cpu().numpy(), g[f"{tag}_latent"])
-    assert r <= TRAJ_TOL, r
+    held(rel_rms(lat.cpu().numpy(), g[f"{tag}_latent"]), TRAJ_TOL, TRAJ_REG, f"g2 {tag} end latent")
 
 
 def test_g5_100m_trajectory():
@@ -176,8 +187,7 @@ def test_g5_100m_trajectory():
     lat = gen.generate_latents(torch.from_numpy(g["traj_labels"]), n_iter=int(g["traj_n_iter"]), num_imgs=1,
                                class_guidance=float(g["traj_class_guidance"]), seeds=torch.from_numpy(g["traj_seeds"]),
                                img_size=32, sharp_f=0.0, bright_f=0.0)
-    r = rel_rms(lat.cpu().numpy(), g["traj_latent"])
-    assert r <= TRAJ_TOL, r
+    held(rel_rms(lat.cpu().numpy(), g["traj_latent"]), TRAJ_TOL, TRAJ_REG, "g5 35-step cfg-6 end latent")
 
 
 def test_full_size_properties_c1():
@@ -201,7 +211,7 @@ def test_full_size_properties_c1():
     # golden inputs embedded in the big batch reproduce the golden output
     x[:2], s[:2], lab[:2] = _t(g["x"]), _t(g["sigma"]), _t(g["label"])
     out2 = m(x, s, lab)
-    assert rel_rms(out2[:2].cpu().numpy(), g["x0"]) <= FWD_TOL
+    held(rel_rms(out2[:2].cpu().numpy(), g["x0"]), FWD_TOL, FWD_REG, "g5 rows inside batch 128")
 
 
 def test_sampler_shard_equivalence_and_cfg_identities():

@@ -249,6 +249,16 @@ struct ProfScope {
     ~ProfScope() { if (on) hipEventRecord(b, s); }
 };
 
+// block 0's MLP hidden tensors (bf16 [M, hid]; debug only, own buffers: they are mlp_multiplier times a residual-stream stage): "blk0_hid" = after the
+// depthwise conv + GELU on whichever path ran, "blk0_hid_pre" = the up-projection's output where it exists in HBM (the two-kernel path)
+int capture_hidden(tld_engine* e, const char* name, const bf16* src, size_t count, hipStream_t s) {
+    if (!e->debug) return TLD_OK;
+    float*& buf = e->stages[name];
+    if (!buf) { if (int rc = dev_alloc(e, &buf, (size_t)e->cfg.max_batch * e->ntok * e->hid)) return rc; }
+    launch_cast_to_f32(src, TLD_DTYPE_BF16, buf, (int64_t)count, s);
+    return TLD_OK;
+}
+
 int capture(tld_engine* e, const char* name, const resid_t* src, size_t count, hipStream_t s) {
     if (!e->debug) return TLD_OK;
     float*& buf = e->stages[name];
@@ -416,6 +426,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
 #endif
                 launch_gemm(g, EPI_BIAS_BF16, s);
             }
+            if (l == 0 && !e->fp8) if (int rc = capture_hidden(e, "blk0_hid_pre", e->hid1, (size_t)M * e->hid, s)) return rc;
             {
                 ProfScope ps(e, KC_DWCONV, s);
                 const bool dw8 = fuse8 && e->grid > 16;       // the tiled kernel writes the fp8 operand of the down projection itself
@@ -423,6 +434,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
                                    dw8 ? e->a8 : nullptr, dw8 ? e->as8 : nullptr);
             }
         }
+        if (l == 0) if (int rc = capture_hidden(e, "blk0_hid", e->hid2, (size_t)M * e->hid, s)) return rc;
         {   // x += hid2 Wdown^T + b
             ProfScope ps(e, KC_GEMM_DOWN, s);
             GemmParams g{};
