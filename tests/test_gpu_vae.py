@@ -1,7 +1,7 @@
 """GPU: the VAE-decode row through the C ABI (tld_vae_* / tld_debug_conv3x3).
 
-Oracle: oracle/vae_ref.py, the fp32 restatement of diffusers' AutoencoderKL.decode (parity unpinned against diffusers
-itself, see its header).  Tolerances: the implicit-GEMM convolution alone is the exact fp32 product of bf16 operands
+Oracle: oracle/vae_ref.py, the fp32 restatement of diffusers' AutoencoderKL.decode (pinned block by block and as a wired decoder against
+transformers' JanusVQVAE* modules -- fixture g18, also used directly here --; unpinned against diffusers itself, see its header).  Tolerances: the implicit-GEMM convolution alone is the exact fp32 product of bf16 operands
 (CONV_TOL, accumulation order only); the decoder keeps bf16 activations between ~30 layers, stated as rel-rms per
 stage / on the image (VAE_STAGE_TOL / VAE_IMAGE_TOL) -- an 8-bit image moves by about one grey level at 1e-2."""
 import ctypes as C
@@ -86,6 +86,51 @@ def test_tiny_decoder_stage_by_stage_against_golden():
     e = rel_rms(img.cpu().numpy(), g["image"])
     assert e < VAE_IMAGE_TOL, e
     vae.set_debug(False)
+
+
+def test_decoder_against_the_published_janus_decoder():
+    """g18 (oracle/gen_golden_vae_blocks.py): stages and images computed by transformers' JanusVQVAEDecoder -- the CompVis decoder AutoencoderKL
+    derives from -- on the synthetic weights: the HIP decoder is held to an implementation the build did not write, with no oracle code at run time.
+    Tiny geometry: every stage in full; SDXL geometry (128, 256, 512, 512) x 2 on 8 x 8 latents: the image in full, stages by a strided sample."""
+    from transformer_latent_diffusion_amd.vae import AutoencoderKLDecoder, VaeDecoderConfig, synth_vae_state_dict
+    g = load_golden("g18_vae_janus.npz")
+    cfg = VaeDecoderConfig(block_out_channels=tuple(int(v) for v in g["blocks_boc"]), layers_per_block=int(g["blocks_layers"]))
+    vae = AutoencoderKLDecoder(cfg, max_batch=2)
+    vae.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vae_state_dict(cfg, int(g["blocks_seed"])).items()})
+    vae.to(_dev())
+    z = torch.from_numpy(g["dec:z"]).to(_dev())
+    vae.decode(z[:1])
+    vae.set_debug(True)
+    img = vae.decode(z)[0]
+    torch.cuda.synchronize()
+    rep = []
+    for key in g:
+        if key.startswith("dec:stage:"):
+            e = rel_rms(vae.read_stage(key[len("dec:stage:"):]).numpy(), g[key])
+            rep.append((key[len("dec:stage:"):], e))
+            assert e < VAE_STAGE_TOL, (key, e)
+    e = rel_rms(img.cpu().numpy(), g["dec:image"])
+    assert e < VAE_IMAGE_TOL, e
+    print("vae vs janus (tiny): " + ", ".join(f"{n} {v:.2e}" for n, v in rep) + f" | image {e:.2e}")
+    cfg2 = VaeDecoderConfig()
+    vae2 = AutoencoderKLDecoder(cfg2, max_batch=1)
+    vae2.load_state_dict({k: torch.from_numpy(v) for k, v in synth_vae_state_dict(cfg2, int(g["sdxl:seed"])).items()})
+    vae2.to(_dev())
+    z2 = torch.from_numpy(g["sdxl:z"]).to(_dev())
+    vae2.decode(z2)
+    vae2.set_debug(True)
+    img2 = vae2.decode(z2)[0]
+    torch.cuda.synchronize()
+    rep = []
+    for n in (str(v) for v in g["sdxl:stage_names"]):
+        f = vae2.read_stage(n).reshape(-1)
+        smp = f[::max(1, f.numel() // 2048)][:2048].numpy()
+        e = rel_rms(smp, g["sdxl:sample:" + n])
+        rep.append((n, e))
+        assert e < VAE_STAGE_TOL * 1.25, (n, e)          # a 2048-element sample of the stage: its rel-rms scatters around the full tensor's
+    e2 = rel_rms(img2.cpu().numpy(), g["sdxl:image"])
+    print("vae vs janus (SDXL geometry): " + ", ".join(f"{n} {v:.2e}" for n, v in rep) + f" | image {e2:.2e}")
+    assert img2.shape == (1, 3, 64, 64) and e2 < VAE_IMAGE_TOL, e2
 
 
 def test_tiny_decoder_matches_the_oracle_on_fresh_inputs_and_is_deterministic():

@@ -206,3 +206,68 @@ def test_engine_batch_limit_follows_the_4gib_buffer_rule():
     assert engine_batch_limit(sdxl, 32) == 127                             # max_batch <= 127 at 256 px
     assert engine_batch_limit(sdxl, 64) == 31 and engine_batch_limit(sdxl, 128) == 7
     assert max_activation_elems(TINY, 8) == max(8 * 8 * 128 * 3, 16 * 16 * 128)
+
+
+# ---- the restatement against an INDEPENDENT PUBLISHED implementation (transformers' JanusVQVAE* = the CompVis decoder AutoencoderKL derives from):
+# ---- fixture g18, written by oracle/gen_golden_vae_blocks.py ----------------------------------------------------------------------------------
+JANUS_TOL = 1e-5          # rel-rms, fp32 vs fp32: summation order only (measured <= 4e-7)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.sqrt(((a - b) ** 2).mean()) / np.sqrt((b ** 2).mean()))
+
+
+def _g18():
+    from conftest import load_golden
+    return load_golden("g18_vae_janus.npz")
+
+
+def test_blocks_match_the_published_janus_vqvae_blocks():
+    """``_resnet`` (equal / unequal channels), ``_attention`` (64 and 144 tokens), ``_upsample`` and ``_mid`` of oracle/vae_ref.py on the inputs and
+    weights the published JanusVQVAEResnetBlock / AttnBlock / ConvUpsample / MidBlock were run on."""
+    g = _g18()
+    cfg = VaeDecoderConfig(block_out_channels=tuple(int(v) for v in g["blocks_boc"]), layers_per_block=int(g["blocks_layers"]))
+    ref = TorchRefVaeDecoder(cfg, synth_vae_state_dict(cfg, int(g["blocks_seed"])))
+    x, xb = torch.from_numpy(g["blk:x128"]), torch.from_numpy(g["blk:x128b"])
+    with torch.no_grad():
+        got = {"resnet_equal": ref._resnet(x, "decoder.mid_block.resnets.0"),
+               "resnet_unequal": ref._resnet(xb, "decoder.up_blocks.1.resnets.0"),
+               "attention": ref._attention(x, "decoder.mid_block.attentions.0"),
+               "attention_b": ref._attention(xb, "decoder.mid_block.attentions.0"),
+               "upsample": ref._upsample(x, "decoder.up_blocks.0.upsamplers.0"),
+               "mid": ref._mid(xb, "decoder.mid_block")}
+    for k, v in got.items():
+        want = g["blk:" + k]
+        assert tuple(v.shape) == want.shape, k
+        assert _rel(v.numpy(), want) <= JANUS_TOL, (k, _rel(v.numpy(), want))
+    assert got["resnet_unequal"].shape[1] == 64          # the 1 x 1 shortcut ran
+
+
+def test_wired_decoder_matches_the_published_janus_decoder_stage_by_stage():
+    g = _g18()
+    cfg = VaeDecoderConfig(block_out_channels=tuple(int(v) for v in g["blocks_boc"]), layers_per_block=int(g["blocks_layers"]))
+    ref = TorchRefVaeDecoder(cfg, synth_vae_state_dict(cfg, int(g["blocks_seed"])))
+    img = ref.decode(torch.from_numpy(g["dec:z"]), keep_stages=True)
+    names = [k[len("dec:stage:"):] for k in g if k.startswith("dec:stage:")]
+    assert sorted(names) == sorted(n for n, _ in ref.stages)
+    for n, t in ref.stages:
+        assert _rel(t.numpy(), g["dec:stage:" + n]) <= JANUS_TOL, (n, _rel(t.numpy(), g["dec:stage:" + n]))
+    assert _rel(img.numpy(), g["dec:image"]) <= JANUS_TOL
+
+
+def test_sdxl_geometry_decoder_matches_the_published_janus_decoder():
+    """(128, 256, 512, 512) x 2 layers per block -- the reference's VAE geometry (tld/configs.py:39-43) -- on 8 x 8 latents: the image in full, every
+    stage by its (mean, rms) and a strided sample."""
+    g = _g18()
+    cfg = VaeDecoderConfig()
+    ref = TorchRefVaeDecoder(cfg, synth_vae_state_dict(cfg, int(g["sdxl:seed"])))
+    img = ref.decode(torch.from_numpy(g["sdxl:z"]), keep_stages=True)
+    assert [n for n, _ in ref.stages] == [str(n) for n in g["sdxl:stage_names"]]
+    for n, t in ref.stages:
+        f = t.reshape(-1)
+        smp = f[::max(1, f.numel() // 2048)][:2048].numpy()
+        assert _rel(smp, g["sdxl:sample:" + n]) <= JANUS_TOL, (n, _rel(smp, g["sdxl:sample:" + n]))
+        mean, rms = g["sdxl:stat:" + n]
+        assert abs(float(f.pow(2).mean().sqrt()) - rms) <= 1e-5 * rms and abs(float(f.mean()) - mean) <= 1e-5 * rms, n
+    assert _rel(img.numpy(), g["sdxl:image"]) <= JANUS_TOL
