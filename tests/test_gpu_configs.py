@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from conftest import cfg_from_arr, load_golden, rel_rms, synth_weights
-from test_gpu_parity import FWD_REG, FWD_TOL, TRAJ_REG, TRAJ_TOL, _dev, _engine, _t, held
+from test_gpu_parity import CFG_FWD_REG, FWD_REG, FWD_TOL, TRAJ_REG, TRAJ_TOL, _dev, _engine, _t, held
 
 pytestmark = pytest.mark.gpu
 
@@ -136,7 +136,7 @@ def test_c3_sampler_512px():
     seeds[0], labels[0] = torch.from_numpy(g["traj_seeds"][0]), torch.from_numpy(g["traj_labels"][0])
     kw = dict(n_iter=int(g["traj_n_iter"]), class_guidance=float(g["traj_class_guidance"]), img_size=64, sharp_f=0.0, bright_f=0.0)
     one, tx0, _ = gen.generate_latents(labels[:1], num_imgs=1, seeds=seeds[:1], trace=True, **kw)
-    held(rel_rms(tx0[0].cpu().numpy(), g["traj_x0_first"]), FWD_TOL, FWD_REG, "C3 first CFG prediction")
+    held(rel_rms(tx0[0].cpu().numpy(), g["traj_x0_first"]), FWD_TOL, CFG_FWD_REG, "C3 first CFG prediction")
     held(rel_rms(one.cpu().numpy(), g["traj_latent"]), TRAJ_TOL, TRAJ_REG, "C3 35-step end latent")
     full = gen.generate_latents(labels, num_imgs=B, seeds=seeds, **kw)
     assert torch.isfinite(full).all() and torch.equal(full[0], one[0])
@@ -154,7 +154,7 @@ def test_c4_sampler_1024px_bf16():
     e0 = rel_rms(tx0[0].cpu().numpy(), g["traj_x0_first"])
     r = rel_rms(one.cpu().numpy(), g["traj_latent"])
     print(f"C4 bf16: first CFG prediction rel-rms {e0:.2e}, 35-step end latent {r:.2e}")
-    held(e0, FWD_TOL, FWD_REG, "C4 bf16 first CFG prediction")
+    held(e0, FWD_TOL, CFG_FWD_REG, "C4 bf16 first CFG prediction")
     held(r, TRAJ_TOL, TRAJ_REG, "C4 bf16 35-step end latent")
 
 

@@ -25,6 +25,8 @@ TRAJ_TOL = 6e-2
 # stays inside 2e-2 but not inside 1e-2.
 FWD_REG = 1e-2
 TRAJ_REG = 2.5e-2
+CFG_FWD_REG = 1.5e-2      # a sampler's FIRST prediction is the CFG combination g * cond + (1 - g) * uncond at g = 6: the difference of two forwards amplifies their
+                          # errors (measured 1.0e-2 at 1024 px, below 1e-2 at 512 px)
 
 
 def held(err, contract, regression, what=""):

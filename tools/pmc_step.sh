@@ -1,9 +1,10 @@
 #!/bin/bash
 # SQ/LDS/TCP counters of every kernel of one C1 denoise generate (counters only, one pass per group).
-# usage (GPU box, repo root): tools/pmc_step.sh gpurun_out/<tag> [kernel-name filter]
+# usage (GPU box, repo root): tools/pmc_step.sh gpurun_out/<tag> [kernel-name filter] [extra bench.py arguments, e.g. "--image-size 64 --images-per-gpu 16"]
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 case $1 in /*) OUT=$1;; *) OUT=$R/$1;; esac
 FILT=${2:-}
+BARGS=${3:-}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -12,7 +13,7 @@ for CNT in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum"; do
   i=$((i+1))
   timeout 600 rocprofv3 --pmc $CNT --output-format csv -d $OUT/p$i -o p -- \
-      python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile > $OUT/p$i.log 2>&1
+      python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-profile $BARGS > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
