@@ -74,6 +74,13 @@ TLD_API int tld_engine_finalize_weights(tld_engine* e);
  * Not in the reference (its model_dtype is fp32 / fp16 / bf16, tld/configs.py:33-37): BASELINE config C4. */
 TLD_API int tld_engine_set_gemm_dtype(tld_engine* e, int32_t dtype);
 
+/* Low-latency capacity class (round 5; no counterpart in the reference, whose serving path -- tld/app.py:48-65 -- runs one prompt per call on whatever
+ * kernels PyTorch picks): for engines of at most 4096 token rows (max_batch x tokens; e.g. 8 images = 16 CFG-doubled samples at 256 px) the MLP down projection of
+ * every block runs as four K-splits + a finishing kernel, which takes a one-image step from 1.7 ms towards 1.2 ms.  Results differ from the default
+ * class in the fp32 summation order of that product (same tolerances against the reference); inside a class they are bit-identical across batch sizes.
+ * May be called any time after tld_engine_create; fails (TLD_ERR_INVALID) on larger engines and on widths other than 384 / 768. */
+TLD_API int tld_engine_set_low_latency(tld_engine* e, int32_t on);
+
 /* Denoiser.forward(x, noise_level, label) -- tld/denoiser.py:116-126 (called at tld/diffusion.py:97-101).
  *   x      [batch, C, S, S]     device, io_dtype
  *   noise  [batch, 1]           device, io_dtype
@@ -110,6 +117,10 @@ TLD_API int tld_engine_read_stage(tld_engine* e, const char* name, float* host_o
  * device inputs, fp32 device output.  K % 64 == 0. */
 TLD_API int tld_debug_gemm_bf16(const void* a_bf16, const void* w_bf16, float* c_f32, int32_t M, int32_t N,
                         int32_t K, void* hip_stream);
+
+/* Test hook: the same product as `ksplit` K-slices, c_slices[s] = A[:, s K/ksplit : (s+1) K/ksplit] . W[:, same]^T (fp32 [ksplit][M][N]).  K % (64 ksplit) == 0. */
+TLD_API int tld_debug_gemm_splitk(const void* a_bf16, const void* w_bf16, float* c_slices_f32, int32_t M, int32_t N, int32_t K, int32_t ksplit,
+                          void* hip_stream);
 
 /* Test hooks of the MX-fp8 path.  quant_mx8: bf16 device matrix [M,K] -> e4m3 bytes [M,K] + E8M0 block scales laid out
  * [K/128][M][4] (device); quant_mx8_host: the weight-side quantiser (fp32 host matrix, host outputs, no GPU needed);

@@ -473,6 +473,59 @@ def test_checkpoint_is_reference_format_and_resumes(tmp_path):
     assert tr3.step == 1 and tr3.global_step == 1001
 
 
+def test_gradient_accumulation_equals_one_large_batch():
+    """accelerator.accumulate() with gradient_accumulation_steps = 2 (tld/train.py:160): two micro-batches of 4 folded with ``last_micro_batch=False`` /
+    default step on the mean of their gradients = the gradient of the mean loss over all 8 samples, i.e. what ONE batch of 8 gives (up to the
+    summation order of the weight-gradient reductions), and the optimizer lands on the same parameters."""
+    from transformer_latent_diffusion_amd import DenoiserConfig, Trainer
+    from transformer_latent_diffusion_amd.train import TrainConfig
+    cfg = DenoiserConfig(image_size=32, n_channels=4)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(8, 4, 32, 32, generator=g) * 0.8; y = torch.randn(8, 768, generator=g) * 0.5
+    nl = torch.rand(8, generator=g) * 0.9 + 0.05; noise = torch.randn(8, 4, 32, 32, generator=g)
+    xn = nl.view(-1, 1, 1, 1) * noise + (1 - nl.view(-1, 1, 1, 1)) * x
+    one = Trainer(cfg, TrainConfig(batch_size=8), device="cuda:0", init_seed=6, max_batch=8, use_graph=False)
+    l_one, _ = one.forward_backward(xn, nl, y, x)
+    g_one = one.grads.clone()
+    acc = Trainer(cfg, TrainConfig(batch_size=8), device="cuda:0", init_seed=6, max_batch=8, use_graph=False)
+    la, _ = acc.forward_backward(xn[:4], nl[:4], y[:4], x[:4], last_micro_batch=False)
+    with pytest.raises(RuntimeError, match="middle of a gradient accumulation"):
+        acc.optimizer_step()
+    lb, _ = acc.forward_backward(xn[4:], nl[4:], y[4:], x[4:])
+    assert abs(0.5 * (float(la) + float(lb)) - float(l_one)) <= 1e-5 * abs(float(l_one)) + 1e-7
+    g_acc = acc.grads * acc._micro_scale                       # optimizer_step applies the 1 / 2
+    rel = float((g_acc - g_one).norm() / g_one.norm())
+    assert rel <= 2e-3, rel                                    # bf16 operands are the same per sample; only fp32 summation orders differ
+    one.optimizer_step(); acc.optimizer_step()
+    assert acc._acc_n == 0 and acc._micro_scale == 1.0 and acc.step == 1
+    d = float((acc.params - one.params).abs().max())
+    assert d <= 2.5 * one.tc.lr, d                             # Adam's first step is lr * sign-like: equal up to sign flips where |g| is at noise level
+    frac = float(((acc.params - one.params).abs() > 1e-6).float().mean())
+    assert frac <= 0.02, frac
+
+
+def test_train_step_stages_host_batches_without_blocking_and_matches_device_batches():
+    """train_step on HOST tensors goes through pinned double buffers and a copy stream (round 5); the result equals forward_backward + optimizer_step
+    on the same batch handed over as device tensors, step after step (graph replay on and off)."""
+    from transformer_latent_diffusion_amd import DenoiserConfig, Trainer
+    from transformer_latent_diffusion_amd.train import TrainConfig
+    cfg = DenoiserConfig(image_size=32, n_channels=4)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 4, 32, 32, generator=g) * 0.8; y = torch.randn(4, 768, generator=g) * 0.5
+    for graph in (True, False):
+        a = Trainer(cfg, TrainConfig(batch_size=4), device="cuda:0", init_seed=2, max_batch=4, use_graph=graph)
+        b = Trainer(cfg, TrainConfig(batch_size=4), device="cuda:0", init_seed=2, max_batch=4, use_graph=False)
+        assert a.use_graph == graph
+        for i in range(4):
+            la = a.train_step(x, y, np_rng=np.random.default_rng(i), generator=torch.Generator().manual_seed(i))
+            xn, nl, lab = b.make_batch(x, y, np.random.default_rng(i), torch.Generator().manual_seed(i))
+            lb, _ = b.forward_backward(xn.cuda(), nl.cuda(), lab.cuda(), x.cuda())
+            b.optimizer_step()
+            assert float(la) == float(lb), (graph, i, float(la), float(lb))
+        torch.cuda.synchronize()
+        assert torch.equal(a.params, b.params), graph
+
+
 def test_trainer_refuses_dropout_and_resolves_current_device():
     from transformer_latent_diffusion_amd import DenoiserConfig, Trainer
     with pytest.raises(NotImplementedError):

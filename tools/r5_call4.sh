@@ -1,0 +1,7 @@
+#!/bin/bash
+O=gpurun_out/r5d; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_configs.py -m gpu -x -q -s -k "split_k or low_latency" > $O/tests_ll.log 2>&1; echo "ll tests rc=$?"; tail -3 $O/tests_ll.log
+timeout 300 python tools/small_batch_latency.py --classes > $O/latency.txt 2>&1; grep "^B=" $O/latency.txt | cut -c1-700
+timeout 1200 python -m pytest tests/test_gpu_train.py -m gpu -x -q > $O/tests_train.log 2>&1; echo "train tests rc=$?"; tail -5 $O/tests_train.log
+timeout 600 python tools/train_bench.py --steps 8 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-600
+TLD_TRAIN_GRAPH=0 timeout 600 python tools/train_bench.py --steps 8 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-600

@@ -20,7 +20,7 @@ KERNEL_CLASSES = ("gemm_qkv", "gemm_up", "gemm_down", "attention", "cross_row", 
 # every symbol include/tld_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = (
     "tld_engine_create", "tld_engine_load_tensor", "tld_engine_finalize_weights", "tld_denoiser_forward",
-    "tld_sample", "tld_engine_set_gemm_dtype", "tld_debug_quant_mx8", "tld_debug_quant_mx8_host", "tld_debug_gemm_mx8",
+    "tld_sample", "tld_engine_set_gemm_dtype", "tld_engine_set_low_latency", "tld_debug_gemm_splitk", "tld_debug_quant_mx8", "tld_debug_quant_mx8_host", "tld_debug_gemm_mx8",
     "tld_engine_set_debug", "tld_engine_read_stage", "tld_debug_gemm_bf16", "tld_debug_gemm_bench",
     "tld_engine_set_profile", "tld_engine_profile_reserve", "tld_engine_get_profile", "tld_engine_weight_bytes", "tld_engine_destroy",
     "tld_vae_create", "tld_vae_load_tensor", "tld_vae_finalize_weights", "tld_vae_decode", "tld_vae_set_debug",
@@ -90,6 +90,8 @@ def lib() -> C.CDLL:
     L.tld_sample.argtypes = [vp, vp, vp, C.POINTER(C.c_float), i32, C.c_float, C.c_float, C.c_float, vp, i32,
                              vp, vp, vp]
     L.tld_engine_set_gemm_dtype.argtypes = [vp, i32]
+    L.tld_engine_set_low_latency.argtypes = [vp, i32]
+    L.tld_debug_gemm_splitk.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
     L.tld_debug_quant_mx8.argtypes = [vp, vp, vp, i32, i32, vp]
     L.tld_debug_quant_mx8_host.argtypes = [C.POINTER(C.c_float), i32, i32, vp, vp]
     L.tld_debug_gemm_mx8.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]

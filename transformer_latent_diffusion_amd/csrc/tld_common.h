@@ -372,6 +372,8 @@ struct GemmParams {
     // group, gn_hw pixels per sample.  Requires gn_hw % 256 == 0 (a tile never straddles samples), N % 128 == 0, gn_cpg % 4 == 0.
     float2* gn_partial;
     int gn_groups, gn_cpg, gn_hw;
+    int ksplit;                   // > 1 (EPI_F32, bf16, no conv): split-K -- K is the length of ONE split, split s multiplies columns [s K, (s + 1) K) of A and W (lda / ldw
+                                  //   = the full row pitch) and writes its fp32 product to c_f32 + s M ldc; the caller sums the slices in a fixed order
     int xcd_ngroups;              // > 1: XCDs form a (8 / G) x G grid over (tile-rows, tile-column groups); needs ntn % G == 0
     // Transposed-operand form (launch_gemm_tn; the weight gradients dW = dY^T X of the training step): A [k rows][lda] and W [k rows][ldw] are
     // both row-major with the CONTRACTION index as the row, C[M, N] = sum_k A[k][m] W[k][n].  tn_ktotal = rows of both operands; K = rows per
@@ -460,6 +462,9 @@ struct CrossRowParams {
 };
 void launch_cross_row(const CrossRowParams& p, hipStream_t s);
 bool cross_row_supports_ln3_stats(int d);
+// split-K finish of the low-latency down projection: x += bias + sum of the fp32 slices (+ LayerNorm-1 partial sums); d = 768 / 384
+bool splitk_resid_supported(int d);
+void launch_splitk_resid(const float* parts, int nsplit, size_t slice_stride, const float* bias, resid_t* x, float2* stats_out, int M, int d, hipStream_t s);
 
 struct TailParams {
     const resid_t* tok;           // [B*N, d]

@@ -120,6 +120,8 @@ struct tld_engine {
     resid_t* x_half = nullptr;         // patch embedding of the un-doubled batch (CFG layer-0 sharing)
     bool share_l0 = true;              // TLD_SHARE_L0=0 disables (A/B testing)
     bool fold_ln1 = true;              // TLD_FOLD_LN1=0: separate LayerNorm-1 kernel (A/B testing)
+    bool low_latency = false;          // tld_engine_set_low_latency: capacity class for small batches (round 5) -- the down projection runs as split-K (see run_body)
+    float* splitk = nullptr;           // [kLowLatSplit][max rows][d] fp32 slices of it
     bool fuse_qkv_attn = true;         // 256-token grids with the LayerNorm-1 fold: QKV GEMM + self-attention as ONE kernel per (sample, head) (TLD_FUSE_QKV_ATTN=0: two kernels)
     float2* ln_stats = nullptr;        // [M][kLnSlots] row partial sums of the residual stream (embed / down GEMM -> QKV GEMM)
     bool fold_ln3 = true;              // TLD_FOLD_LN3=0: cross_row writes LN3(x) and the up-projection reads it (A/B testing)
@@ -251,6 +253,9 @@ struct ProfScope {
 
 // block 0's MLP hidden tensors (bf16 [M, hid]; debug only, own buffers: they are mlp_multiplier times a residual-stream stage): "blk0_hid" = after the
 // depthwise conv + GELU on whichever path ran, "blk0_hid_pre" = the up-projection's output where it exists in HBM (the two-kernel path)
+constexpr int kLowLatSplit = 4;             // K-splits of the low-latency down projection
+constexpr int kLowLatMaxRows = 4096;        // capacity of the low-latency class (token rows = max_batch x tokens): beyond it the tiles fill the chip by themselves
+
 int capture_hidden(tld_engine* e, const char* name, const bf16* src, size_t count, hipStream_t s) {
     if (!e->debug) return TLD_OK;
     float*& buf = e->stages[name];
@@ -331,7 +336,7 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             else launch_layernorm_bf16(half ? xe : e->x, Ly.n1_w, Ly.n1_b, e->xn, Ml, d, s);
         }
         // 256-token grids with the LayerNorm-1 fold: the QKV projection and the whole self-attention of a (sample, head) are one 256 x 192
-        // GEMM tile + epilogue; q | k, v^T never reach HBM and `att` is written directly.  (debug stage dumps and fp8 keep the two kernels)
+        // GEMM tile + epilogue; q | k, v^T never reach HBM and `att` is written directly.  (the fp8 mode keeps the two kernels)
         const bool fused_qa = e->fuse_qkv_attn && fold1 && !e->fp8;
         if (fused_qa) {
             ProfScope ps(e, KC_GEMM_QKV, s);
@@ -435,6 +440,19 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             }
         }
         if (l == 0) if (int rc = capture_hidden(e, "blk0_hid", e->hid2, (size_t)M * e->hid, s)) return rc;
+        if (e->low_latency && !e->fp8) {
+            // Low-latency class: a handful of samples are a handful of 256-row tiles, and the down projection's 48 K-steps per tile (K = 4 d) were
+            // half of a layer's time however empty the chip was.  Four K-splits quadruple the work items (fp32 slices, summed in a fixed order by
+            // the finishing kernel together with bias, residual add and the LayerNorm-1 partial sums).  Results differ from the default class in the
+            // fp32 summation order of that one product -- which is why the class is a property of the ENGINE (chosen by the caller, checked against
+            // its capacity), never of the batch a call happens to carry: inside a class results stay bit-identical across batch sizes.
+            ProfScope ps(e, KC_GEMM_DOWN, s);
+            GemmParams g{};
+            g.A = e->hid2; g.lda = e->hid; g.W = Ly.down_w; g.ldw = e->hid; g.M = M; g.N = d; g.K = e->hid / kLowLatSplit; g.ksplit = kLowLatSplit;
+            g.c_f32 = e->splitk; g.ldc = d;
+            launch_gemm(g, EPI_F32, s);
+            launch_splitk_resid(e->splitk, kLowLatSplit, (size_t)M * d, Ly.down_b, e->x, (fold1 && l + 1 < e->L) ? e->ln_stats : nullptr, M, d, s);
+        } else
         {   // x += hid2 Wdown^T + b
             ProfScope ps(e, KC_GEMM_DOWN, s);
             GemmParams g{};
@@ -946,6 +964,18 @@ int tld_debug_gemm_bf16(const void* a, const void* w, float* c, int32_t M, int32
     return TLD_OK;
 }
 
+int tld_debug_gemm_splitk(const void* a, const void* w, float* c_slices, int32_t M, int32_t N, int32_t K, int32_t ksplit, void* hip_stream) {
+    if (!a || !w || !c_slices) return fail(TLD_ERR_INVALID, "null argument");
+    if (ksplit <= 0 || K <= 0 || K % (64 * ksplit) || M <= 0 || N <= 0) return fail(TLD_ERR_INVALID, "need K %% (64 ksplit) == 0 and positive sizes");
+    if ((int64_t)M * K * 2 >= (int64_t)1 << 32 || (int64_t)N * K * 2 >= (int64_t)1 << 32) return fail(TLD_ERR_INVALID, "operands must be smaller than 4 GiB");
+    GemmParams g{};
+    g.A = static_cast<const bf16*>(a); g.lda = K; g.W = static_cast<const bf16*>(w); g.ldw = K;
+    g.M = M; g.N = N; g.K = K / ksplit; g.ksplit = ksplit; g.c_f32 = c_slices; g.ldc = N;
+    launch_gemm(g, EPI_F32, static_cast<hipStream_t>(hip_stream));
+    HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
 int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t ntok, int32_t iters,
                          double* avg_ms) {
     if (!avg_ms || M <= 0 || N <= 0 || K <= 0 || K % 64 || iters <= 0) return fail(TLD_ERR_INVALID, "bad argument");
@@ -992,6 +1022,21 @@ int tld_debug_gemm_bench(int32_t M, int32_t N, int32_t K, int32_t epilogue, int3
     hipEventDestroy(a); hipEventDestroy(b);
     hipFree(A); hipFree(W); hipFree(out); hipFree(vt); hipFree(bias); hipFree(res); hipFree(dww);
     HIP_TRY(hipGetLastError());
+    return TLD_OK;
+}
+
+int tld_engine_set_low_latency(tld_engine* e, int32_t on) {
+    if (!e) return fail(TLD_ERR_INVALID, "null engine");
+    DeviceGuard dg(e->cfg.device_id);
+    if (!on) { e->low_latency = false; return TLD_OK; }
+    const int64_t rows = (int64_t)e->cfg.max_batch * e->ntok;
+    if (rows > kLowLatMaxRows)
+        return fail(TLD_ERR_INVALID, "low-latency class: engine capacity %lld token rows (max_batch %d x %d tokens) exceeds %d -- at that size the default tiles fill the chip",
+                    (long long)rows, e->cfg.max_batch, e->ntok, kLowLatMaxRows);
+    if (!e->fold_ln1 || !splitk_resid_supported(e->d) || e->hid % (64 * kLowLatSplit) != 0)
+        return fail(TLD_ERR_INVALID, "low-latency class: needs the bf16-residual build with the LayerNorm-1 fold and embed_dim 384 or 768 (got %d)", e->d);
+    if (!e->splitk) { if (int rc = dev_alloc(e, &e->splitk, (size_t)kLowLatSplit * rows * e->d)) return rc; }
+    e->low_latency = true;
     return TLD_OK;
 }
 

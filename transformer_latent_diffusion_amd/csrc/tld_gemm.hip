@@ -136,7 +136,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 
     const int ntn = (p.N + BN - 1) / BN;
     const int ntm = (p.M + G::BM - 1) / G::BM;
-    const int ntiles = ntm * ntn;
+    // split-K (GemmParams::ksplit; fp32 slices, two-stage loop only): the tile list is `ksplit` copies of the (m, n) grid, copy s multiplying
+    // the K range [s K, (s + 1) K) of both operands into output slice s
+    constexpr bool KSPLIT_OK = EPI == EPI_F32 && !F8 && !CONV && !RING && !TN;
+    const int nsplit = (KSPLIT_OK && p.ksplit > 1) ? p.ksplit : 1;
+    const int ntiles = ntm * ntn * nsplit;
+    int kb_dec = 0;                                                    // K byte offset of the tile tile_coords() decoded last
     // static schedule: XCD x (= block id % 8, where the dispatcher puts this block) owns a contiguous run of the
     // tile order; its workgroups take that run round-robin
     const int bid = blockIdx.x;
@@ -181,7 +186,14 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             m0 = (r0 + tm) * G::BM;
             n0 = (xn * gcols + (t - tm * gcols)) * BN;
         } else {
-            const int tile = xbase + t;
+            int tile = xbase + t;
+            if constexpr (KSPLIT_OK) {
+                if (nsplit > 1) {
+                    const int sp = tile / (ntm * ntn);
+                    tile -= sp * (ntm * ntn);
+                    kb_dec = sp * p.K * 2;
+                }
+            }
             const int tm = tile / ntn;
             m0 = tm * G::BM;
             n0 = (tile - tm * ntn) * BN;
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
         char* st = smem + (g & 1) * G::STAGE_BYTES;
         set_offsets(m0, n0);
 #pragma unroll
-        for (int q2 = 0; q2 < G::A_PIECES + G::B_PIECES; ++q2) dma_piece(q2, 0, st);
+        for (int q2 = 0; q2 < G::A_PIECES + G::B_PIECES; ++q2) dma_piece(q2, KSPLIT_OK ? kb_dec : 0, st);     // (called right after tile_coords of that tile)
         dma_scales(m0, n0, 0, g & 1);
     };
     // ks: 16-element k-slice (bf16: 4 per K-step) / 64-element k-slice (fp8: 2 per K-step)
@@ -479,6 +491,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 
     int m0, n0;
     tile_coords(0, m0, n0);
+    int kb0 = kb_dec, kbn = 0;                        // split-K: K byte offset of the current / next tile (0 without splits)
     if constexpr (!RING) issue(m0, n0, 0);
     int g = 0;                                        // global K-step counter (ring position)
     int ctap = 0, ccb = 0;                            // CONV: (tap, 64-channel block) of the K-step whose DMA was issued last
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     for (int it = 0; it < my_tiles; ++it) {
         int m0n = 0, n0n = 0;
         const bool has_next = it + 1 < my_tiles;
-        if (has_next) tile_coords(it + 1, m0n, n0n);
+        if (has_next) { tile_coords(it + 1, m0n, n0n); kbn = kb_dec; }
         // MFMA operand order: swapped (D^T = W A^T: a lane owns a token row and 4 consecutive columns per register quad)
         // everywhere except the fp32 debug epilogue.  The V^T tiles of the QKV GEMM are swapped too and transposed on
         // their way through the epilogue scratch with 2-byte LDS writes: one K-loop instantiation instead of two took
@@ -603,7 +616,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 const char* st = smem + (g & 1) * G::STAGE_BYTES;
                 char* nst = smem + ((g + 1) & 1) * G::STAGE_BYTES;
                 const bool more = (k + 1 < nkt) || (has_next && !UPDW);
-                const int pkb = (k + 1 < nkt) ? (k + 1) * G::BK * 2 : 0;
+                const int pkb = (k + 1 < nkt) ? (KSPLIT_OK ? kb0 : 0) + (k + 1) * G::BK * 2 : (KSPLIT_OK ? kbn : 0);
                 if constexpr (CONV) {
                     if (k + 1 < nkt) {
                         if (++ccb == kpt) { ccb = 0; ++ctap; conv_tap(ctap); }
@@ -838,7 +851,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = row0 + i * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
-                        if (row < p.M) p.c_f32[(size_t)row * p.ldc + col] = acc[i][j][r];
+                        if (row < p.M) p.c_f32[(KSPLIT_OK && nsplit > 1 ? (size_t)(kb0 / (p.K * 2)) * p.M * p.ldc : (size_t)0) + (size_t)row * p.ldc + col] = acc[i][j][r];
                     }
                 }
         } else {
@@ -1457,7 +1470,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 }
             }
         }
-        m0 = m0n; n0 = n0n;
+        m0 = m0n; n0 = n0n; kb0 = kbn;
     }
 }
 
@@ -1466,7 +1479,8 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     using G = G256P<BN>;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + G::BM - 1) / G::BM;
     const int ncu = device_cu_count();
-    const int nblocks = ntm * ntn < ncu ? ntm * ntn : ncu;
+    const int nsplit = (epilogue == EPI_F32 && !p.f8 && !p.conv && p.ksplit > 1) ? p.ksplit : 1;
+    const int nblocks = ntm * ntn * nsplit < ncu ? ntm * ntn * nsplit : ncu;
     dim3 grid(nblocks), block(512);
     // Up-projection (12 tile-columns at d = 768): two column groups x four tile-row blocks over the 8 XCDs keep each
     // XCD's W working set at 2.4 MB (L2-resident across rounds; it was re-fetched every round, PMC fetch 296 MB vs
@@ -1474,7 +1488,7 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     // four groups for the up-projection (neutral), two / four groups for the down-projection (A is the 201 MB
     // operand there: neutral / 175 -> 195 us).  Large launches only: every XCD cell needs workgroups of its own.
     // half-tile ring K loop (256 x 256 tiles, bf16, no conv): an iteration is two K-tiles, so K must be a multiple of 128
-    const bool use_ring = p.conv ? (9 * (p.cv_cin >> 6)) % 2 == 0 : (p.K >= 128 && p.K % 128 == 0);      // (conv: K = 9 cv_cin, an even number of 64-wide K-tiles)
+    const bool use_ring = nsplit > 1 ? false : p.conv ? (9 * (p.cv_cin >> 6)) % 2 == 0 : (p.K >= 128 && p.K % 128 == 0);      // (conv: K = 9 cv_cin, an even number of 64-wide K-tiles)
     (void)use_ring;
     GemmParams pg = p;
     static const bool half_tail = !(getenv("TLD_GEMM_HALFTAIL") && atoi(getenv("TLD_GEMM_HALFTAIL")) == 0);     // test hook: tests/test_gpu_parity.py holds the row-split tail bitwise equal to the unsplit run
@@ -1601,6 +1615,7 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
         if (epilogue == EPI_BIAS_RESID && p.N % 192 == 0 && ((ntm * (p.N / 192)) % 256 == 0 || p.N % 256 != 0)) bn = 192;
         else bn = (p.N % 256 == 0) ? 256 : 128;
     }
+    if (epilogue == EPI_F32 && p.ksplit > 1 && !p.f8 && !p.conv) bn = 128;     // split-K: the narrow tile has no ring instantiation to fall into and gives the most work items
     // (A column-split QKV launch -- 8 tile-columns of 256 as 4 whole rounds + the 9th as 128-wide tiles -- was
     // measured: 109.8 + 27.8 us vs 134 us for the single 4.5-round launch; a one-round launch pays ~12 us of
     // ramp/drain, so the half-empty fifth round is the cheaper tail.)

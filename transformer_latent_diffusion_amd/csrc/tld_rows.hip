@@ -1336,6 +1336,60 @@ void launch_cross_row(const CrossRowParams& p, hipStream_t s) {
     TLD_DISPATCH_D(p.d, { TLD_LDS_OPT_IN((cross_row_kernel<NJ, HALF>), lds); hipLaunchKernelGGL((cross_row_kernel<NJ, HALF>), grid, dim3(256), lds, s, p, (int)cps); });
 }
 
+// ------------------------------------------------------------------------------------------------
+// Low-latency class (round 5): the down projection of a SMALL batch as split-K -- `nsplit` fp32 slices from the persistent GEMM -- finished here:
+//   x[row] = bf16(x[row] + bias + slice_0[row] + ... + slice_{nsplit-1}[row])     (fixed order)   tld/transformer_blocks.py:104,138
+// plus the LayerNorm-1 partial sums (sum, sum of squares of the ROUNDED row per 96-column group) the next block's fused QKV kernel reads --
+// what EPI_BIAS_RESID does in its own epilogue.  One wave per row, lane l owns columns [CPL l, CPL (l + 1)): a group is 96 / CPL adjacent lanes.
+template <int CPL>
+__global__ __launch_bounds__(256) void splitk_resid_kernel(const float* __restrict__ parts, int nsplit, size_t slice_stride, const float* __restrict__ bias,
+                                                           resid_t* __restrict__ x, float2* __restrict__ stats_out, int M) {
+    constexpr int d = CPL * 64, GL = 96 / CPL;                  // lanes per statistics group (8 at d = 768, 16 at d = 384)
+    static_assert(96 % CPL == 0 && (GL & (GL - 1)) == 0 && CPL % 2 == 0, "a 96-column group must be a power-of-two run of lanes");
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float v[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c += 2) {
+        const float2 b2 = *reinterpret_cast<const float2*>(bias + CPL * lane + c);
+        v[c] = b2.x; v[c + 1] = b2.y;
+    }
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const float* src = parts + sp * slice_stride + (size_t)row * d + CPL * lane;
+#pragma unroll
+        for (int c = 0; c < CPL; c += 2) {
+            const float2 t = *reinterpret_cast<const float2*>(src + c);
+            v[c] += t.x; v[c + 1] += t.y;
+        }
+    }
+    resid_t* px = x + (size_t)row * d + CPL * lane;
+    float su = 0.f, sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < CPL; c += 2) {
+        const float2 xv = rs_load2(px + c);
+        const float o0 = xv.x + v[c], o1 = xv.y + v[c + 1];
+        rs_store2(px + c, make_float2(o0, o1));
+        const float r0 = rs_round(o0), r1 = rs_round(o1);
+        su += r0 + r1;
+        sq = fmaf(r0, r0, fmaf(r1, r1, sq));
+    }
+    if (stats_out) {
+#pragma unroll
+        for (int o2 = 1; o2 < GL; o2 <<= 1) { su += __shfl_xor(su, o2, 64); sq += __shfl_xor(sq, o2, 64); }
+        const int slot = lane / GL;
+        if ((lane & (GL - 1)) == 0 && slot < kLnSlots) stats_out[(size_t)row * kLnSlots + slot] = make_float2(su, sq);
+    }
+}
+
+bool splitk_resid_supported(int d) { return d == 768 || d == 384; }
+
+void launch_splitk_resid(const float* parts, int nsplit, size_t slice_stride, const float* bias, resid_t* x, float2* stats_out, int M, int d, hipStream_t s) {
+    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    if (d == 768) hipLaunchKernelGGL(splitk_resid_kernel<12>, grid, block, 0, s, parts, nsplit, slice_stride, bias, x, stats_out, M);
+    else if (d == 384) hipLaunchKernelGGL(splitk_resid_kernel<6>, grid, block, 0, s, parts, nsplit, slice_stride, bias, x, stats_out, M);
+}
+
 void launch_tail(const TailParams& p, hipStream_t s) {
 #ifdef TLD_RESID_BF16
     if (p.w_hl && p.d % 128 == 0 && (long)p.pd * p.d <= 40960) {      // matrix-pipe form: split-bf16 weights [2][pd][d] in <= 160 KiB of LDS (the XOR swizzle of its

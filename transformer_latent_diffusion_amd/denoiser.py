@@ -56,6 +56,7 @@ class Denoiser:
         self._engine_batch = 0
         self._engine_device = None
         self._gemm_dtype = 0              # 0: bf16 operands; 1: MX-fp8 QKV / MLP GEMMs (set_gemm_dtype)
+        self._low_latency = False         # capacity class for small batches (set_low_latency): split-K down projection
         self.training = False
 
     # ---- nn.Module-like surface ------------------------------------------------------------------
@@ -137,7 +138,7 @@ class Denoiser:
             return self._engine
         self._drop_engine()
         L = _lib.lib()
-        cap = max(model_batch, 8)
+        cap = model_batch if self._low_latency else max(model_batch, 8)       # (the low-latency class is bounded by capacity: no head-room there)
         cfg = _lib.TldConfig(self.image_size, self.noise_embed_dims, self.patch_size, self.embed_dim, self.n_layers,
                              self.text_emb_size, self.n_channels, self.mlp_multiplier, cap, dev.index)
         h = C.c_void_p()
@@ -145,6 +146,8 @@ class Denoiser:
         try:
             if self._gemm_dtype:
                 _lib.check(L.tld_engine_set_gemm_dtype(h, self._gemm_dtype), "tld_engine_set_gemm_dtype")
+            if self._low_latency:
+                _lib.check(L.tld_engine_set_low_latency(h, 1), "tld_engine_set_low_latency")
             for k, t in self._state.items():
                 if t.dtype == torch.int64:
                     continue
@@ -166,6 +169,20 @@ class Denoiser:
         if code != self._gemm_dtype:
             self._drop_engine()
         self._gemm_dtype = code
+        return self
+
+    LOW_LATENCY_MAX_ROWS = 4096          # engine capacity (model batch x tokens) of the low-latency class: kLowLatMaxRows in csrc/tld_engine.hip
+
+    def set_low_latency(self, on: bool = True) -> "Denoiser":
+        """Serve SMALL batches in the low-latency capacity class (``tld_engine_set_low_latency``): the MLP down projection of every block runs as
+        split-K, which cuts a one-image denoise step from ~1.7 ms to ~1.2 ms (the reference's serving pattern is one prompt per call,
+        tld/app.py:48-65).  The class is a property of this model object, not of a call: every engine it builds is in the class, results inside it
+        are bit-identical across batch sizes, and they differ from the default class only in the fp32 summation order of that product.  A batch
+        whose CFG-doubled size x tokens exceeds ``LOW_LATENCY_MAX_ROWS`` raises -- build a second model object for bulk generation."""
+        on = bool(on)
+        if on != self._low_latency:
+            self._drop_engine()
+        self._low_latency = on
         return self
 
     def reserve(self, model_batch: int, device=None) -> "Denoiser":

@@ -95,7 +95,7 @@ class Trainer:
     def __init__(self, denoiser_cfg: DenoiserConfig, train_cfg: Optional[TrainConfig] = None, device="cuda",
                  state_dict: Optional[Mapping[str, torch.Tensor]] = None, init_seed: int = 0, max_batch: Optional[int] = None,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, keep_ema: bool = True, process_group=None,
-                 overlap_allreduce: bool = True):
+                 overlap_allreduce: bool = True, use_graph: Optional[bool] = None):
         self.cfg = denoiser_cfg
         self.tc = train_cfg if train_cfg is not None else TrainConfig()
         dev = torch.device(device)
@@ -134,10 +134,13 @@ class Trainer:
             self._h = None
             raise
         self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-        # Optional HIP-graph replay of forward + backward (TLD_TRAIN_GRAPH=1 or use_graph=True): the step is ~1 900 small launches with
-        # static shapes; captured once (on the second full-batch call, after an eager warm-up) and replayed from fixed input buffers, it
-        # takes the host out of the loop.  Adam stays outside (its step count is a kernel argument).
-        self.use_graph = bool(int(os.environ.get("TLD_TRAIN_GRAPH", "0")))
+        # HIP-graph replay of forward + backward: the step is ~1 900 small launches with static shapes; captured once (on the second full-batch
+        # call, after an eager warm-up) and replayed from fixed input buffers, it takes the host out of the loop.  Adam stays outside (its step
+        # count is a kernel argument).  Round 5: ON by default for a single replica (TLD_TRAIN_GRAPH=0 / use_graph=False: eager launches) -- on a
+        # slow host the eager step's wall time was 44 ms against 31 ms of device time; with more than one rank the eager path stays the default,
+        # because the per-block gradient all-reduces are launched from a host callback in the middle of the backward (not capturable).
+        env = os.environ.get("TLD_TRAIN_GRAPH")
+        self.use_graph = bool(int(env)) if env is not None else (use_graph if use_graph is not None else self._world() == 1)
         self.overlap_allreduce = overlap_allreduce
         self._comm_stream = None
         self._pending = []                # async all-reduce handles of the gradient slices of the step in flight
@@ -148,6 +151,15 @@ class Trainer:
         self._graph = None
         self._graph_calls = 0
         self._static = None
+        # gradient accumulation over micro-batches (accelerator.accumulate(), tld/train.py:160)
+        self._acc = None                  # flat fp32 sum of the gradients of the micro-batches folded so far
+        self._acc_n = 0
+        self._micro_scale = 1.0           # 1 / (micro-batches of the step): applied by the optimizer kernel together with 1 / world
+        # host -> device staging of train_step's batch: pinned double buffers + a copy stream, so that the host never blocks on a pageable copy
+        # that is stream-ordered behind the previous step's kernels (that stall made the eager step's wall time device + enqueue time)
+        self._stage = [None, None]
+        self._stage_i = 0
+        self._copy_stream = None
 
     def _check_layout(self):
         L = _lib.lib()
@@ -229,9 +241,15 @@ class Trainer:
         mask = torch.rand(y.size(0), generator=generator) < LABEL_DROPOUT
         return mix_noise(x, noise_level, noise), noise_level.float(), drop_labels(y, mask)
 
-    def forward_backward(self, x_noisy: torch.Tensor, noise_level: torch.Tensor, label: torch.Tensor, target: torch.Tensor):
+    def forward_backward(self, x_noisy: torch.Tensor, noise_level: torch.Tensor, label: torch.Tensor, target: torch.Tensor, *,
+                         last_micro_batch: bool = True):
         """zero_grad + forward + MSE + backward (tld/train.py:163-168).  Returns (loss [1] on the device, pred); the gradients are in
-        ``self.grads`` (flat) / ``grad_dict()``."""
+        ``self.grads`` (flat) / ``grad_dict()``.
+
+        Gradient accumulation (``accelerator.accumulate()``, tld/train.py:160, with ``gradient_accumulation_steps`` = n > 1): call n - 1 times
+        with ``last_micro_batch=False`` and once with the default; ``optimizer_step()`` then steps on the MEAN of the n micro-batch gradients
+        (equal micro-batch sizes: the gradient of the mean loss).  Like DDP's ``no_sync`` the ranks exchange nothing until the last micro-batch:
+        the accumulated sum is reduced by ONE all-reduce in ``optimizer_step``."""
         dev = self.device
         t = lambda a: a.detach().to(dev, torch.float32).contiguous()
         xn, nl, lab, tgt = t(x_noisy), t(noise_level).view(-1), t(label), t(target)
@@ -240,7 +258,8 @@ class Trainer:
             raise ValueError("inconsistent batch shapes")
         if B > self.max_batch:
             raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
-        overlap = self.overlap_allreduce and self._world() > 1 and not (self.use_graph and B == self.max_batch)
+        accumulating = (not last_micro_batch) or self._acc_n > 0
+        overlap = self.overlap_allreduce and self._world() > 1 and not (self.use_graph and B == self.max_batch) and not accumulating
         self.wait_gradients()             # a previous call's slice reductions may still be running on the communication stream: they read / write self.grads
         self._slices = []
         self._cb_error = None
@@ -300,10 +319,27 @@ class Trainer:
                     for dst, src in zip(self._static[:4], (xn, nl, lab, tgt)):
                         dst.copy_(src)
                 self._graph.replay()
-                return self._loss, self._static[4].clone()         # (a copy: the static buffer is overwritten by the next replay)
+                return self._fold_micro_batch(last_micro_batch), self._static[4].clone()         # (a copy: the static buffer is overwritten by the next replay)
         pred = torch.empty_like(xn)
         launch(xn, nl, lab, tgt, pred)
-        return self._loss, pred
+        return self._fold_micro_batch(last_micro_batch), pred
+
+    def _fold_micro_batch(self, last: bool) -> torch.Tensor:
+        """Gradient accumulation bookkeeping after a forward_backward; returns the loss tensor to hand out (a copy while accumulating: the engine
+        overwrites its loss cell on the next micro-batch)."""
+        if last and self._acc_n == 0:
+            self._micro_scale = 1.0
+            return self._loss
+        if self._acc is None:
+            self._acc = torch.zeros_like(self.grads)
+        if last:                                  # grads <- sum of all micro-batch gradients; the optimizer kernel divides by their number
+            self.grads.add_(self._acc)
+            self._micro_scale = 1.0 / (self._acc_n + 1)
+            self._acc.zero_(); self._acc_n = 0
+        else:
+            self._acc.add_(self.grads)
+            self._acc_n += 1
+        return self._loss.clone()
 
     def _world(self) -> int:
         import torch.distributed as dist
@@ -347,6 +383,10 @@ class Trainer:
             scale = 1.0 / self._world()
         else:
             scale = allreduce_mean_(self.grads, self.group)
+        if self._acc_n:
+            raise RuntimeError(f"optimizer_step in the middle of a gradient accumulation ({self._acc_n} micro-batches folded, none marked last)")
+        scale *= self._micro_scale
+        self._micro_scale = 1.0
         self.step += 1
         self.global_step += 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -361,9 +401,52 @@ class Trainer:
         """One iteration of the reference's inner loop on the batch (x, y) as the loader yields it (x already divided by the VAE scale
         factor, :119).  Returns the loss tensor (device, not synchronised)."""
         x_noisy, noise_level, label = self.make_batch(x, y, np_rng, generator)
-        loss, _ = self.forward_backward(x_noisy, noise_level, label, x)
+        staged = self._stage_batch((x_noisy, noise_level, label, x))
+        loss, _ = self.forward_backward(*staged)
+        self._release_stage()
         self.optimizer_step()
         return loss
+
+    def _stage_batch(self, arrs):
+        """Host tensors -> device through pinned double buffers on a copy stream (see __init__); device tensors pass through."""
+        if not all(isinstance(a, torch.Tensor) and a.device.type == "cpu" for a in arrs):
+            return arrs
+        dev = self.device
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=dev)
+        i = self._stage_i = self._stage_i ^ 1
+        shapes = tuple(tuple(a.shape) for a in arrs)
+        st = self._stage[i]
+        compute = torch.cuda.current_stream(dev)
+        if st is None or st["shapes"] != shapes:
+            # the device buffers are allocated ON the copy stream: the caching allocator recycles blocks per stream, and a block just released by the
+            # compute stream (say the previous step's prediction copy, its kernel still queued) must not come back here and be written by the copy
+            # stream ahead of that kernel -- the first version of this did exactly that and trained on a corrupted batch
+            with torch.cuda.stream(self._copy_stream):
+                devb = [torch.empty(a.shape, dtype=torch.float32, device=dev) for a in arrs]
+            for t_ in devb:
+                t_.record_stream(compute)
+            st = {"shapes": shapes, "host": [torch.empty(a.shape, dtype=torch.float32).pin_memory() for a in arrs], "dev": devb, "copied": None, "free": None}
+            self._stage[i] = st
+        if st["copied"] is not None:
+            st["copied"].synchronize()            # the copy that last read these pinned buffers (two steps ago: long done)
+        for h, a in zip(st["host"], arrs):
+            h.copy_(a)
+        if st["free"] is not None:
+            self._copy_stream.wait_event(st["free"])      # the step that last read these device buffers has finished with them
+        with torch.cuda.stream(self._copy_stream):
+            for d, h in zip(st["dev"], st["host"]):
+                d.copy_(h, non_blocking=True)
+            st["copied"] = torch.cuda.Event()
+            st["copied"].record(self._copy_stream)
+        compute.wait_event(st["copied"])
+        return tuple(st["dev"])
+
+    def _release_stage(self):
+        st = self._stage[self._stage_i]
+        if st is not None:
+            st["free"] = torch.cuda.Event()
+            st["free"].record(torch.cuda.current_stream(self.device))
 
     # ---- checkpoint / resume ----------------------------------------------------------------------------------------------------
     def optimizer_state_dict(self) -> Dict[str, object]:
