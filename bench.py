@@ -56,7 +56,7 @@ def class_flops(cls, M, d, ntok, n_layers, fused_attention=False):
 def pmc_traffic(cls):
     """HBM bytes per launch of a GEMM class from the committed PMC passes (tools/pmc_traffic.sh: separate
     FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x 2 gfx950 correction).  None if no profile is committed."""
-    path = next((q for q in (os.path.join(REPO, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (4, 3, 2, 1)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(REPO, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), None)
     if path is None:
         return None, None
     epis = {"gemm_qkv": (", 7>", ", 7,", ", 1>", ", 5>", ", 1,", ", 5,"), "gemm_up": (", 6>", ", 4>", ", 2>", ", 6,", ", 4,", ", 2,"),

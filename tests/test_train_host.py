@@ -109,3 +109,36 @@ def test_gradient_allreduce_two_ranks_gloo(tmp_path):
                         "--master-port", "29561", str(script)], capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_overlapped_reduction_bookkeeping_without_a_device():
+    """Host logic of the overlapped gradient all-reduce: the recorded slices must tile the flat gradient vector exactly once before
+    the optimizer takes the 1 / world path; gradient accumulation refuses an optimizer step in the middle of a step's micro-batches."""
+    from transformer_latent_diffusion_amd.train import Trainer
+    tr = Trainer.__new__(Trainer)                      # no engine: only the bookkeeping fields
+    tr.numel = 100
+    tr._slices = [(60, 40), (0, 25), (25, 35)]         # arrival order does not matter
+    assert tr._slices_tile_vector()
+    tr._slices = [(60, 40), (0, 25)]                   # a slice never arrived (its all-reduce raised inside the ctypes callback)
+    assert not tr._slices_tile_vector()
+    tr._slices = [(0, 60), (50, 50)]                   # overlap
+    assert not tr._slices_tile_vector()
+    tr._slices = []
+    assert not tr._slices_tile_vector()
+    tr._pending, tr._reduced = [], True
+    tr.group = None
+    with pytest.raises(RuntimeError, match="partly reduced"):
+        tr.optimizer_step()
+    assert tr._reduced is False                        # the flag does not survive the refusal
+
+
+def test_two_bound_helper_reports_which_bound_failed():
+    """tests/test_gpu_parity.held: the contract tolerance and the tighter regression bound fail with different messages."""
+    from test_gpu_parity import FWD_REG, FWD_TOL, held
+    held(6.3e-3, FWD_TOL, FWD_REG, "ok")
+    with pytest.raises(AssertionError, match="regression"):
+        held(1.5e-2, FWD_TOL, FWD_REG, "between the bounds")
+    with pytest.raises(AssertionError, match="parity"):
+        held(3e-2, FWD_TOL, FWD_REG, "outside the contract")
+    with pytest.raises(AssertionError, match="parity"):
+        held(float("nan"), FWD_TOL, FWD_REG, "nan")

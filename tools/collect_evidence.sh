@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy what tools/round_evidence.sh left under gpurun_out/<tag> into profiles/<prefix>_*: tools/collect_evidence.sh r04b r04
-T=${1:-r04}; P=${2:-r04}; O=gpurun_out/$T
+T=${1:-r05}; P=${2:-r05}; O=gpurun_out/$T
 cp $O/bench_c1.json profiles/${P}_bench_c1.json
 cp $O/bench_c3.json profiles/${P}_bench_c3.json
 cp $O/bench_c4_bf16.json profiles/${P}_bench_c4_bf16.json

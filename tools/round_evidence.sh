@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box call that refreshes the evidence of a round under gpurun_out/<tag> (copied into profiles/ afterwards):
 # full GPU suite, PMC traffic (C1), bench lines C1 (with cpu_baseline) / C3 / C4 bf16 / C4 fp8 (8 images per GPU), rocprofv3 kernel stats, parity report.
-T=${1:-r04}; P=${2:-r04}      # tag under gpurun_out, file prefix under profiles/
+T=${1:-r05}; P=${2:-r05}      # tag under gpurun_out, file prefix under profiles/
 O=gpurun_out/$T
 mkdir -p $O
 timeout 900 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1; echo "tests rc=$?"; tail -2 $O/tests.log

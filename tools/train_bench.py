@@ -63,7 +63,7 @@ line = {"metric": "training samples/sec (100M denoiser, 32x32x4 latents, fwd + b
         "config": {"workload": f"training step, 100M-param denoiser (d=768, L={args.layers}), batch {args.batch}, Adam lr 3e-4, EMA 0.999"},
         "loss": float(loss), "algorithmic_tflops": step_tflop / ddt, "frac_of_bf16_mfma_peak": step_tflop / ddt / 2500.0,
         "roofline": {"bound": "mfma", "achieved": step_tflop / ddt, "peak": 2500.0, "unit": "TFLOP/s", "frac": step_tflop / ddt / 2500.0,
-                     "note": "whole step (3 x the reference forward op count) over the device-only step time; per-kernel times: profiles/r03_train_kernel_stats.csv"}}
+                     "note": "whole step (3 x the reference forward op count) over the device-only step time; per-kernel times: profiles/r05_train_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this tool)"}}
 if not args.no_cpu_baseline:
     from oracle.torch_ref import train_step_reference
     from transformer_latent_diffusion_amd.weights import synth_state_dict
