@@ -53,9 +53,12 @@ def class_flops(cls, M, d, ntok, n_layers, fused_attention=False):
     return f * (n_layers - 0.5) / n_layers + (att if fused_attention else 0.0) if cls == "gemm_qkv" else f
 
 
-def pmc_traffic(cls):
+def pmc_traffic(cls, image_size=32, gemm_dtype="bf16"):
     """HBM bytes per launch of a GEMM class from the committed PMC passes (tools/pmc_traffic.sh: separate
-    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x 2 gfx950 correction).  None if no profile is committed."""
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x 2 gfx950 correction).  None if no profile is committed FOR THIS WORKLOAD:
+    the committed passes are of the C1 line (256 px, bf16); the C3 / C4 lines carry traffic = null."""
+    if image_size != 32 or gemm_dtype != "bf16":
+        return None, None
     path = next((q for q in (os.path.join(REPO, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), None)
     if path is None:
         return None, None
@@ -352,7 +355,7 @@ def main():
             ach = fl(dom) / avg_s / 1e12
             tot_f = sum(fl(c) * prof[c][1] for c in prof)
             tot_t = sum(prof[c][0] for c in prof) / 1e3
-            traffic, traffic_src = pmc_traffic(dom)
+            traffic, traffic_src = pmc_traffic(dom, S, args.gemm_dtype)
             # dense MFMA peak of the dominant class's operand type (MI355X_MICROARCH.md): bf16 2.5 PF, MX-fp8 5 PF
             peak = 2 * MFMA_PEAK_TFLOPS if (args.gemm_dtype == "fp8" and dom != "attention") else MFMA_PEAK_TFLOPS
             line["roofline"] = {
