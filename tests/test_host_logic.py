@@ -57,6 +57,12 @@ def test_denoiser_facade_contract():
         m(torch.zeros(2, 4, 16, 16), torch.zeros(2, 1), torch.zeros(2, 768))
     with pytest.raises(NotImplementedError):
         m.train()
+    # the low-latency capacity class is a property of the model object: chainable, no engine needed to choose it, still no CPU path behind it
+    assert m.set_low_latency(True) is m and m._low_latency and m.set_low_latency(False) is m and not m._low_latency
+    m.set_low_latency(True)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(2, 4, 16, 16), torch.zeros(2, 1), torch.zeros(2, 768))
+    assert Denoiser.LOW_LATENCY_MAX_ROWS == 4096
 
 
 def test_generator_shell_without_gpu_fails_loudly_and_checks_labels():
