@@ -330,6 +330,26 @@ def test_low_latency_class_vs_golden_and_inside_the_class():
         odd(torch.zeros(1, 4, 32, 32, device=_dev()), torch.full((1, 1), 0.5, device=_dev()), torch.zeros(1, 768, device=_dev()))
 
 
+@pytest.mark.parametrize("tag", ["d384", "n1024_d384", "n64_d768", "mlp2_d768"])
+def test_low_latency_class_on_other_shapes_vs_golden(tag):
+    """The low-latency class away from the 100 M shape, against the reference's own forwards (g16): d = 384 (the finishing kernel's 6-columns-per-lane
+    instantiation) at 256 and 1024 tokens, d = 768 at 64 tokens, and mlp_multiplier = 2 (hidden width 1536: four K-splits of 384).  Bit-identical across
+    batch sizes inside the class here too."""
+    from transformer_latent_diffusion_amd import Denoiser
+    g = load_golden("g16_config_sweep.npz")
+    cfg = cfg_from_arr(g[f"{tag}_cfg"])
+    sd = synth_weights(cfg, g["weight_seed"], g[f"{tag}_checksum"])
+    m = Denoiser(**asdict(cfg)).to(_dev()).set_low_latency(True)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    x, s, lab = g[f"{tag}_x"], g[f"{tag}_sigma"], g[f"{tag}_label"]
+    out = m(_t(x), _t(s), _t(lab)).cpu().numpy()
+    r = rel_rms(out, g[f"{tag}_x0"])
+    assert np.isfinite(out).all() and r <= FWD_TOL, (tag, r)
+    rep = 2 if tag.startswith("n1024") else 3                      # stays inside the class's 4096 token rows
+    big = m(_t(np.tile(x, (rep, 1, 1, 1))), _t(np.tile(s, (rep, 1))), _t(np.tile(lab, (rep, 1)))).cpu().numpy()
+    assert np.array_equal(big[:2], out) and np.array_equal(big[-2:], out), tag
+
+
 def _stress_model(g, tag, env):
     from transformer_latent_diffusion_amd import Denoiser
     cfg = cfg_from_arr(g["cfg"])

@@ -504,6 +504,40 @@ def test_gradient_accumulation_equals_one_large_batch():
     assert frac <= 1e-3, frac                                  # (measured 1e-6)
 
 
+def test_gradient_accumulation_under_graph_replay_and_ragged_staging():
+    """Accumulation with the forward + backward replayed from the HIP graph (full micro-batches) lands on the parameters of the eager path, step after step;
+    and train_step's pinned staging follows a batch whose size changes (the last, smaller batch of an epoch) and changes back."""
+    from transformer_latent_diffusion_amd import DenoiserConfig, Trainer
+    from transformer_latent_diffusion_amd.train import TrainConfig
+    cfg = DenoiserConfig(image_size=32, n_channels=4)
+    g = torch.Generator().manual_seed(12)
+    mk = lambda n: (torch.randn(n, 4, 32, 32, generator=g) * 0.8, torch.rand(n, generator=g) * 0.9 + 0.05, torch.randn(n, 768, generator=g) * 0.5,
+                    torch.randn(n, 4, 32, 32, generator=g))
+    batches = [mk(4) for _ in range(6)]
+    res = {}
+    for graph in (True, False):
+        tr = Trainer(cfg, TrainConfig(batch_size=4), device="cuda:0", init_seed=4, max_batch=4, use_graph=graph)
+        for i in range(0, 6, 2):
+            tr.forward_backward(*batches[i], last_micro_batch=False)
+            tr.forward_backward(*batches[i + 1])
+            tr.optimizer_step()
+        torch.cuda.synchronize()
+        assert (tr._graph is not None) == graph and tr.step == 3
+        res[graph] = tr.params.clone()
+    assert torch.equal(res[True], res[False])
+    a = Trainer(cfg, TrainConfig(batch_size=4), device="cuda:0", init_seed=4, max_batch=4)
+    b = Trainer(cfg, TrainConfig(batch_size=4), device="cuda:0", init_seed=4, max_batch=4, use_graph=False)
+    x, y = torch.randn(4, 4, 32, 32, generator=g) * 0.8, torch.randn(4, 768, generator=g) * 0.5
+    for i, n in enumerate((4, 4, 3, 4, 2, 4)):
+        la = a.train_step(x[:n], y[:n], np_rng=np.random.default_rng(i), generator=torch.Generator().manual_seed(i))
+        xn, nl, lab = b.make_batch(x[:n], y[:n], np.random.default_rng(i), torch.Generator().manual_seed(i))
+        lb, _ = b.forward_backward(xn.cuda(), nl.cuda(), lab.cuda(), x[:n].cuda())
+        b.optimizer_step()
+        assert float(la) == float(lb), (i, n, float(la), float(lb))
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, b.params)
+
+
 def test_train_step_stages_host_batches_without_blocking_and_matches_device_batches():
     """train_step on HOST tensors goes through pinned double buffers and a copy stream (round 5); the result equals forward_backward + optimizer_step
     on the same batch handed over as device tensors, step after step (graph replay on and off)."""

@@ -1033,8 +1033,8 @@ int tld_engine_set_low_latency(tld_engine* e, int32_t on) {
     if (rows > kLowLatMaxRows)
         return fail(TLD_ERR_INVALID, "low-latency class: engine capacity %lld token rows (max_batch %d x %d tokens) exceeds %d -- at that size the default tiles fill the chip",
                     (long long)rows, e->cfg.max_batch, e->ntok, kLowLatMaxRows);
-    if (!e->fold_ln1 || !splitk_resid_supported(e->d) || e->hid % (64 * kLowLatSplit) != 0)
-        return fail(TLD_ERR_INVALID, "low-latency class: needs the bf16-residual build with the LayerNorm-1 fold and embed_dim 384 or 768 (got %d)", e->d);
+    if (!splitk_resid_supported(e->d) || e->hid % (64 * kLowLatSplit) != 0)
+        return fail(TLD_ERR_INVALID, "low-latency class: needs embed_dim 384 or 768 (got %d) and a hidden width that splits into %d multiples of 64 (got %d)", e->d, kLowLatSplit, e->hid);
     if (!e->splitk) { if (int rc = dev_alloc(e, &e->splitk, (size_t)kLowLatSplit * rows * e->d)) return rc; }
     e->low_latency = true;
     return TLD_OK;
