@@ -125,11 +125,14 @@ def test_overlapped_reduction_bookkeeping_without_a_device():
     assert not tr._slices_tile_vector()
     tr._slices = []
     assert not tr._slices_tile_vector()
-    tr._pending, tr._reduced = [], True
+    tr._pending, tr._reduced, tr._acc_n = [], True, 0
     tr.group = None
     with pytest.raises(RuntimeError, match="partly reduced"):
         tr.optimizer_step()
     assert tr._reduced is False                        # the flag does not survive the refusal
+    tr._acc_n = 2
+    with pytest.raises(RuntimeError, match="middle of a gradient accumulation"):
+        tr.optimizer_step()
 
 
 def test_two_bound_helper_reports_which_bound_failed():

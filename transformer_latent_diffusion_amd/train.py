@@ -263,6 +263,7 @@ class Trainer:
         self.wait_gradients()             # a previous call's slice reductions may still be running on the communication stream: they read / write self.grads
         self._slices = []
         self._cb_error = None
+        self._reduced = False             # (a previous overlapped call that was never stepped on must not vouch for THIS call's gradients)
         cb = None
         if overlap:
             import torch.distributed as dist
@@ -374,6 +375,8 @@ class Trainer:
     def optimizer_step(self) -> None:
         """DDP gradient mean + Adam + EMA (tld/train.py:168-172).  The gradient sum over the ranks is either already in flight (per-block slices
         started during the backward, ``overlap_allreduce``) or one all-reduce of the flat vector here."""
+        if self._acc_n:
+            raise RuntimeError(f"optimizer_step in the middle of a gradient accumulation ({self._acc_n} micro-batches folded, none marked last)")
         if self._reduced:
             self._reduced = False
             self.wait_gradients()         # the current stream waits for the slices' reductions
@@ -383,8 +386,6 @@ class Trainer:
             scale = 1.0 / self._world()
         else:
             scale = allreduce_mean_(self.grads, self.group)
-        if self._acc_n:
-            raise RuntimeError(f"optimizer_step in the middle of a gradient accumulation ({self._acc_n} micro-batches folded, none marked last)")
         scale *= self._micro_scale
         self._micro_scale = 1.0
         self.step += 1
