@@ -691,13 +691,15 @@ int tld_engine_finalize_weights(tld_engine* e) {
             HIP_TRY(hipMemcpy(Ly.qkv_c1, c1.data(), c1.size() * 4, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(Ly.qkv_b1, b1.data(), b1.size() * 4, hipMemcpyHostToDevice));
             e->weight_bytes += (int64_t)wf.size() * 2 + (int64_t)c1.size() * 8;
-            if (e->fuse_qkv_attn) {     // rows [q; k; v] x [head][64]  ->  [head][q_h | k_h | v_h]: tile-column h of the fused kernel is head h
+            if (e->fuse_qkv_attn) {     // rows [q; k; v] x [head][64]  ->  [head][feature half][q | k | v][32]: tile-column h of the fused kernel is head h, and each of
+                // its two 96-column wave columns holds 32 features of q, of k AND of v -- so the slow part of the image write (V^T: 2-byte scattered LDS writes) is
+                // shared by all eight waves instead of falling on the four that held v (round 5; the values and their accumulation order do not change)
                 std::vector<uint16_t> wp(wf.size());
                 std::vector<float> c1p(c1.size()), b1p(b1.size());
                 for (int64_t h = 0; h < e->H; ++h)
                     for (int part = 0; part < 3; ++part)
                         for (int64_t c = 0; c < 64; ++c) {
-                            const int64_t src = part * d + h * 64 + c, dst = h * 192 + part * 64 + c;
+                            const int64_t src = part * d + h * 64 + c, dst = h * 192 + (c >> 5) * 96 + part * 32 + (c & 31);
                             memcpy(&wp[(size_t)(dst * d)], &wf[(size_t)(src * d)], (size_t)d * 2);
                             c1p[(size_t)dst] = c1[(size_t)src]; b1p[(size_t)dst] = b1[(size_t)src];
                         }

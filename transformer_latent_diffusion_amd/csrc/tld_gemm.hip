@@ -1236,11 +1236,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                 char* Kimg = smem + G::AT_K;
                 char* Vimg = smem + G::AT_V;
                 char* Qimg = smem + G::AT_Q;
-                // tile columns: [0, 64) q, [64, 128) k, [128, 192) v.  Wave column 0 owns q and k features 0-31, wave column 1 k features
-                // 32-63 and v (wn is wave-uniform: scalar branches)
+                // tile columns (host-side row order of the packed weight, tld_engine.hip): wave column wn = feature half, its three 32-column blocks j = q, k, v of
+                // features 32 wn .. 32 wn + 31 -- every wave writes a third of its values to each image
 #pragma unroll
                 for (int j = 0; j < G::TN; ++j) {
-                    const int cbase = wn * G::WCOLS + j * 32;       // 0, 32, 64 | 96, 128, 160
 #pragma unroll
                     for (int i = 0; i < G::TM; ++i) {
                         const int row = wm * G::WROWS + i * 32 + e_l31;
@@ -1249,12 +1248,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                             bf16x4 pk;
                             pk[0] = (bf16)acc[i][j][rq * 4 + 0]; pk[1] = (bf16)acc[i][j][rq * 4 + 1];
                             pk[2] = (bf16)acc[i][j][rq * 4 + 2]; pk[3] = (bf16)acc[i][j][rq * 4 + 3];
-                            if (cbase < 128) {
-                                const int f = (cbase & 63) + 8 * rq + 4 * e_hi;        // feature inside q or k
-                                char* img = cbase < 64 ? Qimg : Kimg;
+                            const int f = wn * 32 + 8 * rq + 4 * e_hi;                 // feature inside q, k or v
+                            if (j < 2) {
+                                char* img = j == 0 ? Qimg : Kimg;
                                 *reinterpret_cast<bf16x4*>(img + row * 128 + ((((f >> 3) ^ ((row >> 1) & 7)) << 4) | ((f & 7) << 1))) = pk;
                             } else {
-                                const int f = cbase - 128 + 8 * rq + 4 * e_hi;
 #pragma unroll
                                 for (int e2 = 0; e2 < 4; ++e2)
                                     *reinterpret_cast<bf16*>(Vimg + (f + e2) * kAttnVPitch + row * 2) = pk[e2];
