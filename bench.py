@@ -54,20 +54,27 @@ def class_flops(cls, M, d, ntok, n_layers, fused_attention=False):
 
 
 def pmc_traffic(cls, image_size=32, gemm_dtype="bf16"):
-    """HBM bytes per launch of a GEMM class from the committed PMC passes (tools/pmc_traffic.sh: separate
-    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x 2 gfx950 correction).  None if no profile is committed FOR THIS WORKLOAD:
-    the committed passes are of the C1 line (256 px, bf16); the C3 / C4 lines carry traffic = null."""
-    if image_size != 32 or gemm_dtype != "bf16":
+    """HBM bytes per launch of a GEMM / attention class from the committed PMC passes (tools/pmc_traffic.sh: separate
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE x 2 gfx950 correction) OF THIS WORKLOAD: profiles/rNN_pmc_traffic.json is the C1
+    line (256 px, bf16), rNN_pmc_traffic_c3.json the 512 px line, rNN_pmc_traffic_c4_bf16.json / _c4_fp8.json the 1024 px lines.
+    None if no pass of the workload is committed."""
+    suffix = {(32, "bf16"): "", (64, "bf16"): "_c3", (128, "bf16"): "_c4_bf16", (128, "fp8"): "_c4_fp8"}.get((image_size, gemm_dtype))
+    if suffix is None:
         return None, None
-    path = next((q for q in (os.path.join(REPO, "profiles", f"r{r:02d}_pmc_traffic.json") for r in (5, 4, 3, 2, 1)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(REPO, "profiles", f"r{r:02d}_pmc_traffic{suffix}.json") for r in (6, 5, 4, 3, 2, 1)) if os.path.exists(q)), None)
     if path is None:
         return None, None
-    epis = {"gemm_qkv": (", 7>", ", 7,", ", 1>", ", 5>", ", 1,", ", 5,"), "gemm_up": (", 6>", ", 4>", ", 2>", ", 6,", ", 4,", ", 2,"),
-            "gemm_down": (", 3>", ", 3,"), "attention": ("attn",)}[cls]       # 4 / 6 = up-projection fused with dwconv + GELU
+    # template arguments <BN, EPI, F8, ...> of gemm256p_kernel: EPI 7 / 5 / 1 = the QKV forms, 6 / 4 / 2 = the up-projection forms, 3 = residual add
+    epis = {"gemm_qkv": (", 7>", ", 7,", ", 1>", ", 5>", ", 1,", ", 5,"), "gemm_up": (", 6>", ", 4>", ", 2>", ", 6,", ", 4,", ", 2,", ", 8,", ", 8>"),
+            "gemm_down": (", 3>", ", 3,"), "attention": ("attn",)}[cls]       # 4 / 6 / 8 = up-projection fused with dwconv + GELU
+    best = None
     for name, v in json.load(open(path)).items():
-        if ("gemm256p_kernel" in name or cls == "attention") and any(e in name for e in epis):
-            return v["hbm_bytes_per_launch"], f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)"
-    return None, None
+        if (("gemm256p_kernel" in name and cls != "attention") or (cls == "attention" and "attn" in name and "gemm256p" not in name)) and any(e in name for e in epis):
+            if best is None or v["hbm_bytes_per_launch"] * v["launches"] > best["hbm_bytes_per_launch"] * best["launches"]:
+                best = v
+    if best is None:
+        return None, None
+    return best["hbm_bytes_per_launch"], f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same workload)"
 
 
 def model_flops(cfg, ntok, share_l0=True):

@@ -78,8 +78,8 @@ TLD_API int tld_engine_set_gemm_dtype(tld_engine* e, int32_t dtype);
  * kernels PyTorch picks): for engines of at most 4096 token rows (max_batch x tokens; e.g. 8 images = 16 CFG-doubled samples at 256 px) the MLP down projection of
  * every block runs as four K-splits + a finishing kernel, which takes a one-image step from 1.7 ms towards 1.2 ms.  Results differ from the default
  * class in the fp32 summation order of that product (same tolerances against the reference); inside a class they are bit-identical across batch sizes.
- * May be called any time after tld_engine_create; fails (TLD_ERR_INVALID) on larger engines, on widths other than 384 / 768 and on hidden widths that do not split
- * into four multiples of 64. */
+ * May be called any time after tld_engine_create; fails (TLD_ERR_INVALID) on larger engines, on widths other than 384 / 768, on hidden widths that do not split
+ * into four multiples of 64, and on engines in the MX-fp8 GEMM mode (bf16 operands only; tld_engine_set_gemm_dtype(fp8) likewise refuses an engine of this class). */
 TLD_API int tld_engine_set_low_latency(tld_engine* e, int32_t on);
 
 /* Denoiser.forward(x, noise_level, label) -- tld/denoiser.py:116-126 (called at tld/diffusion.py:97-101).

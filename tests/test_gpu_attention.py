@@ -39,6 +39,7 @@ def _ref(q, k, v):
 
 @pytest.mark.parametrize("N,B,H,scale", [(64, 3, 2, 1.0), (128, 2, 4, 1.0), (256, 3, 12, 1.0), (512, 2, 12, 1.0), (768, 1, 3, 1.0), (1024, 2, 12, 1.0), (1280, 1, 2, 2.0),
                                          (1024, 1, 4, 3.0), (2048, 1, 2, 6.0), (4096, 1, 2, 1.0),
+                                         (1024, 1, 1, 1.0), (512, 3, 3, 1.0), (768, 5, 2, 1.0),      # (sample, head) pair counts that are not multiples of the 8 XCDs: attn2's padded 1-D grid (round 6)
                                          (16, 5, 2, 1.0), (144, 3, 4, 1.0), (400, 2, 6, 2.0), (576, 2, 12, 1.0), (2008, 1, 2, 1.0)])   # masked chunked kernel: partial last chunk / query block
 def test_attention_forward_vs_fp32(N, B, H, scale):
     g = torch.Generator().manual_seed(N + 7 * B + H)

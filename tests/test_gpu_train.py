@@ -498,10 +498,42 @@ def test_gradient_accumulation_equals_one_large_batch():
     assert rel <= 1e-5, rel                                    # bf16 operands are the same per sample; only fp32 summation orders differ (measured 6e-8)
     one.optimizer_step(); acc.optimizer_step()
     assert acc._acc_n == 0 and acc._micro_scale == 1.0 and acc.step == 1
+    assert one.global_step == 1 and acc.global_step == 2       # the loop counter counts micro-batches (tld/train.py:162-174), Adam's count optimizer steps
     d = float((acc.params - one.params).abs().max())
     assert d <= 0.1 * one.tc.lr, d                             # Adam's first step is lr * g / (|g| + eps): differs only where |g| is at the 1e-8 eps level (measured 0.007 lr)
     frac = float(((acc.params - one.params).abs() > 1e-6).float().mean())
     assert frac <= 1e-3, frac                                  # (measured 1e-6)
+
+
+def test_abandoned_accumulation_can_be_reset_and_explicit_use_graph_beats_the_environment(monkeypatch):
+    """(a) a step abandoned in the middle of an accumulation must not poison the next one -- reset_accumulation() drops the folded
+    gradients (load_state_dict does it too); (b) an explicit use_graph= argument wins over TLD_TRAIN_GRAPH."""
+    from transformer_latent_diffusion_amd import DenoiserConfig, Trainer
+    from transformer_latent_diffusion_amd.train import TrainConfig
+    cfg = DenoiserConfig(image_size=32, n_channels=4)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(4, 4, 32, 32, generator=g) * 0.8; y = torch.randn(4, 768, generator=g) * 0.5
+    nl = torch.rand(4, generator=g) * 0.9 + 0.05; noise = torch.randn(4, 4, 32, 32, generator=g)
+    xn = nl.view(-1, 1, 1, 1) * noise + (1 - nl.view(-1, 1, 1, 1)) * x
+    monkeypatch.setenv("TLD_TRAIN_GRAPH", "1")
+    ref = Trainer(cfg, TrainConfig(batch_size=4), device="cuda:0", init_seed=6, max_batch=4, use_graph=False)
+    assert ref.use_graph is False
+    monkeypatch.delenv("TLD_TRAIN_GRAPH")
+    ref.forward_backward(xn, nl, y, x)
+    g_ref = ref.grads.clone()
+    tr = Trainer(cfg, TrainConfig(batch_size=4), device="cuda:0", init_seed=6, max_batch=4, use_graph=False)
+    tr.forward_backward(xn.flip(0), nl.flip(0), y.flip(0), x.flip(0), last_micro_batch=False)      # ... and the step is abandoned here
+    with pytest.raises(RuntimeError, match="reset_accumulation"):
+        tr.optimizer_step()
+    tr.reset_accumulation()
+    assert tr._acc_n == 0 and tr._micro_scale == 1.0 and float(tr._acc.abs().max()) == 0.0
+    tr.forward_backward(xn, nl, y, x)
+    assert torch.equal(tr.grads, g_ref)                       # nothing of the abandoned micro-batch is left in the gradients
+    tr.optimizer_step()
+    assert tr.step == 1 and tr.global_step == 2
+    tr.forward_backward(xn, nl, y, x, last_micro_batch=False)
+    tr.load_state_dict(ref.state_dict())
+    assert tr._acc_n == 0
 
 
 def test_gradient_accumulation_under_graph_replay_and_ragged_staging():

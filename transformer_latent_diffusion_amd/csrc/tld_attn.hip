@@ -552,17 +552,27 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int N> __device__ __forceinline__ void a2_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Round 6: XCD-local block order.  The grid used to be (query block, head, sample) with the query block fastest, so the ntok / 256 workgroups that share one
+//     (sample, head)'s K / V^T were dealt round-robin over the 8 XCDs and EVERY XCD's L2 fetched every pair's K / V^T: 1.74 GB per launch at C4 against
+//     0.40 GB algorithmic, 483 MB against 201 at C3 (gpurun_out/r06_base PMC passes; after: profiles/r06_pmc_traffic_c4_*.json / _c3.json).  Time is unchanged -- the kernel is VALU-issue-bound, not fetch-bound
+//     (profiles/r06_attn2_prescaled_experiment.txt) -- the traffic is what the order is for.  Now the grid is 1-D: workgroup L runs on
+//     XCD L & 7 (where the dispatcher puts it) and takes query block (L >> 3) % gx of pair ((L >> 3) / gx) * 8 + (L & 7) -- the gx workgroups of a pair are
+//     consecutive workgroups of ONE XCD, resident at the same time, and walk the key chunks together.
 __global__ __launch_bounds__(256, 2) void attn2_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ vt,
-                                                       bf16* __restrict__ att, int ntok, int d) {
+                                                       bf16* __restrict__ att, int ntok, int d, int heads, int npairs) {
     constexpr int KC = 128, KB = KC * 128, VB = 64 * KC * 2, TP = 16 * 144;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int gx = ntok >> 8;
+    const int jb = (int)blockIdx.x >> 3;
+    const int pair = (jb / gx) * 8 + ((int)blockIdx.x & 7);
+    if (pair >= npairs) return;                       // (the grid is padded to 8 pairs per round)
+    const int b = pair / heads, h = pair - b * heads;
     const int hi = lane >> 5, l31 = lane & 31;
     const int twod = 2 * d;
     const size_t row_base = (size_t)b * ntok;
-    const int q0 = blockIdx.x * 256 + wid * 64;
+    const int q0 = (jb - (jb / gx) * gx) * 256 + wid * 64;
     const int nchunks = ntok / KC;
 #if TLD_A2_CLK
     const uint64_t clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
@@ -577,27 +587,40 @@ __global__ __launch_bounds__(256, 2) void attn2_kernel(const bf16* __restrict__ 
     }
     const bf16* kbase0 = qk + row_base * twod + d + h * 64;
     const bf16* vbase0 = vt + ((size_t)b * d + h * 64) * ntok;
+    // DMA addressing as in the GEMM: a uniform 64-bit base (SGPR pair, advanced per chunk) + one 32-bit per-lane byte offset per piece, rebuilt from the
+    // lane id where it is used (8 pieces per 128-key chunk: a few VALU instructions each) instead of per-lane 64-bit pointers kept across the chunk loop:
+    // 243 -> 221 VGPRs
     auto stage_k = [&](int ch) {            // LDS row r of the chunk <- key pi(r): quads 1 and 2 of every 16 rows swapped
-        const bf16* kb = kbase0 + (size_t)ch * KC * twod;
+        const char* kb = reinterpret_cast<const char*>(kbase0) + (size_t)ch * KC * twod * 2;
+        asm volatile("" : "+s"(kb));
         char* dst = smem + (ch & 1) * KB;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int piece = wid * 4 + it;
-            const int r = piece * 8 + (lane >> 3);
+            const int r = piece * 8 + (ln >> 3);
             const int key = (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
-            const int clog = (lane & 7) ^ ((r >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((gptr_t)(kb + (size_t)key * twod + clog * 8), (lptr_t)(dst + piece * 1024), 16, 0, 0);
+            const int clog = (ln & 7) ^ ((r >> 1) & 7);
+            unsigned o = (unsigned)(key * twod + clog * 8) * 2u;
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gptr_t)(kb + o), (lptr_t)(dst + piece * 1024), 16, 0, 0);
         }
     };
     auto stage_v = [&](int ch) {            // [64 features][128 keys], 16-byte chunk c of row f at chunk c ^ (f & 15)
-        const bf16* vb = vbase0 + (size_t)ch * KC;
+        const char* vb = reinterpret_cast<const char*>(vbase0) + (size_t)ch * KC * 2;
+        asm volatile("" : "+s"(vb));
         char* dst = smem + 2 * KB + (ch & 1) * VB;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int piece = wid * 4 + it;
-            const int f = piece * 4 + (lane >> 4);
-            const int c = (lane & 15) ^ (f & 15);
-            __builtin_amdgcn_global_load_lds((gptr_t)(vb + (size_t)f * ntok + c * 8), (lptr_t)(dst + piece * 1024), 16, 0, 0);
+            const int f = piece * 4 + (ln >> 4);
+            const int c = (ln & 15) ^ (f & 15);
+            unsigned o = (unsigned)(f * ntok + c * 8) * 2u;
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + o), (lptr_t)(dst + piece * 1024), 16, 0, 0);
         }
     };
     // lane parts of the fragment addresses: K row l31, chunk (2 ks + hi) ^ ((l31 >> 1) & 7);  V^T row l31 (+32 ct), chunk (2 s + hi) ^ (l31 & 15)
@@ -808,7 +831,9 @@ void launch_attn2(const bf16* qk, const bf16* vt, bf16* att, int batch, int ntok
     constexpr int lds = 2 * 128 * 128 + 2 * 64 * 256 + 4 * 16 * 144;
     static PerDeviceOnce attr_set;
     attr_set.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(attn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
-    hipLaunchKernelGGL(attn2_kernel, dim3(ntok / 256, heads, batch), dim3(256), lds, s, qk, vt, att, ntok, heads * 64);
+    const int npairs = batch * heads;
+    const int nblocks = ((npairs + 7) / 8) * 8 * (ntok / 256);         // pairs padded to whole rounds of the 8 XCDs (the surplus workgroups return at once)
+    hipLaunchKernelGGL(attn2_kernel, dim3(nblocks), dim3(256), lds, s, qk, vt, att, ntok, heads * 64, heads, npairs);
 }
 
 }  // namespace

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <stdint.h>
 
 namespace tld {
@@ -275,15 +276,20 @@ struct PerDeviceOnce {
     }
 };
 struct PerDeviceMax {                                // largest value requested so far on the current device
+    // The attribute call and the publication of the new maximum are ONE critical section: two threads that first-launch the same kernel
+    // on one device with different sizes could otherwise leave the attribute at the smaller value while the cache says the larger one
+    // (round-5 advisor finding).  The fast path -- the cached value already covers the request -- stays lock-free.
     std::atomic<int> v[64] = {};
+    std::mutex mu;
     template <class F> void run(int want, F&& set_attribute) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         std::atomic<int>& a = v[dev & 63];
-        int cur = a.load(std::memory_order_acquire);
-        if (cur >= want) return;
+        if (a.load(std::memory_order_acquire) >= want) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (a.load(std::memory_order_relaxed) >= want) return;       // another thread raised it while this one waited
         set_attribute();
-        while (cur < want && !a.compare_exchange_weak(cur, want, std::memory_order_release, std::memory_order_acquire)) {}
+        a.store(want, std::memory_order_release);
     }
 };
 // device that owns a device pointer (debug hooks that take raw pointers and no engine); -1 if unknown

@@ -1031,6 +1031,8 @@ int tld_engine_set_low_latency(tld_engine* e, int32_t on) {
     if (!e) return fail(TLD_ERR_INVALID, "null engine");
     DeviceGuard dg(e->cfg.device_id);
     if (!on) { e->low_latency = false; return TLD_OK; }
+    if (e->fp8)
+        return fail(TLD_ERR_INVALID, "low-latency class: bf16 GEMM operands only -- this engine runs MX-fp8 GEMMs (tld_engine_set_gemm_dtype), whose down projection has no split-K form");
     const int64_t rows = (int64_t)e->cfg.max_batch * e->ntok;
     if (rows > kLowLatMaxRows)
         return fail(TLD_ERR_INVALID, "low-latency class: engine capacity %lld token rows (max_batch %d x %d tokens) exceeds %d -- at that size the default tiles fill the chip",
@@ -1047,6 +1049,7 @@ int tld_engine_set_gemm_dtype(tld_engine* e, int32_t dtype) {
     if (e->finalized) return fail(TLD_ERR_STATE, "the GEMM operand type must be chosen before tld_engine_finalize_weights");
     if (dtype != 0 && dtype != 1) return fail(TLD_ERR_INVALID, "gemm dtype %d: 0 = bf16, 1 = MX-fp8 (e4m3 + E8M0 block scales)", dtype);
     if (dtype == 1) {
+        if (e->low_latency) return fail(TLD_ERR_INVALID, "fp8 GEMMs and the low-latency class exclude each other (the split-K down projection is bf16 only): clear tld_engine_set_low_latency first");
 #ifndef TLD_RESID_BF16
         return fail(TLD_ERR_INVALID, "the fp8 GEMM mode exists in the bf16-residual build only");
 #endif

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 from collections import OrderedDict
 from dataclasses import asdict, dataclass
 from typing import Dict, Mapping, Optional, Tuple
@@ -139,8 +140,12 @@ class Trainer:
         # count is a kernel argument).  Round 5: ON by default for a single replica (TLD_TRAIN_GRAPH=0 / use_graph=False: eager launches) -- on a
         # slow host the eager step's wall time was 44 ms against 31 ms of device time; with more than one rank the eager path stays the default,
         # because the per-block gradient all-reduces are launched from a host callback in the middle of the backward (not capturable).
+        # precedence: the explicit constructor argument, then TLD_TRAIN_GRAPH, then the default (one replica: on).  The world size is read
+        # here; a process group initialised later does not flip the choice, so a graph step with more than one rank (which gives up the
+        # overlapped per-block all-reduce for full batches) is announced once, at the first such step (forward_backward).
         env = os.environ.get("TLD_TRAIN_GRAPH")
-        self.use_graph = bool(int(env)) if env is not None else (use_graph if use_graph is not None else self._world() == 1)
+        self.use_graph = bool(use_graph) if use_graph is not None else (bool(int(env)) if env is not None else self._world() == 1)
+        self._graph_world_warned = False
         self.overlap_allreduce = overlap_allreduce
         self._comm_stream = None
         self._pending = []                # async all-reduce handles of the gradient slices of the step in flight
@@ -229,6 +234,8 @@ class Trainer:
         a = self._angular.numpy()
         _lib.check(_lib.lib().tld_train_set_angular_speeds(self._h, a.ctypes.data_as(C.POINTER(C.c_float)), a.size), "tld_train_set_angular_speeds")
         _lib.check(_lib.lib().tld_train_bind(self._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(self.grads.data_ptr())), "tld_train_bind")
+        if getattr(self, "_acc_n", 0):
+            self.reset_accumulation()                             # gradients folded against the old weights mean nothing for the new ones
         return self
 
     # ---- the step -------------------------------------------------------------------------------------------------------------
@@ -259,6 +266,10 @@ class Trainer:
         if B > self.max_batch:
             raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
         accumulating = (not last_micro_batch) or self._acc_n > 0
+        if self.use_graph and B == self.max_batch and self._world() > 1 and self.overlap_allreduce and not self._graph_world_warned:
+            self._graph_world_warned = True
+            warnings.warn("Trainer: HIP-graph replay is on with more than one rank -- full batches reduce their gradients with ONE all-reduce after the "
+                          "backward instead of the per-block slices under it (use_graph=False / TLD_TRAIN_GRAPH=0 restores the overlap)", RuntimeWarning)
         overlap = self.overlap_allreduce and self._world() > 1 and not (self.use_graph and B == self.max_batch) and not accumulating
         self.wait_gradients()             # a previous call's slice reductions may still be running on the communication stream: they read / write self.grads
         self._slices = []
@@ -327,7 +338,11 @@ class Trainer:
 
     def _fold_micro_batch(self, last: bool) -> torch.Tensor:
         """Gradient accumulation bookkeeping after a forward_backward; returns the loss tensor to hand out (a copy while accumulating: the engine
-        overwrites its loss cell on the next micro-batch)."""
+        overwrites its loss cell on the next micro-batch).  ``global_step`` advances HERE, once per micro-batch: the reference counts loader
+        iterations (``global_step += 1`` after every pass through ``accelerator.accumulate()``, tld/train.py:162-174), so checkpoints and the
+        ``save_and_eval_every_iters`` cadence keep its meaning with accumulation on.  One stated deviation remains for n > 1 micro-batches: the
+        reference calls ``update_ema`` in every iteration (on unchanged weights between optimizer steps), this trainer once per optimizer step."""
+        self.global_step += 1
         if last and self._acc_n == 0:
             self._micro_scale = 1.0
             return self._loss
@@ -341,6 +356,14 @@ class Trainer:
             self._acc.add_(self.grads)
             self._acc_n += 1
         return self._loss.clone()
+
+    def reset_accumulation(self) -> None:
+        """Abandon a gradient accumulation in progress (an exception in a later micro-batch, a skipped bad batch): the folded gradients are
+        dropped and the next forward_backward starts a fresh step.  Also called when weights or a checkpoint are loaded."""
+        if self._acc is not None:
+            self._acc.zero_()
+        self._acc_n = 0
+        self._micro_scale = 1.0
 
     def _world(self) -> int:
         import torch.distributed as dist
@@ -376,7 +399,8 @@ class Trainer:
         """DDP gradient mean + Adam + EMA (tld/train.py:168-172).  The gradient sum over the ranks is either already in flight (per-block slices
         started during the backward, ``overlap_allreduce``) or one all-reduce of the flat vector here."""
         if self._acc_n:
-            raise RuntimeError(f"optimizer_step in the middle of a gradient accumulation ({self._acc_n} micro-batches folded, none marked last)")
+            raise RuntimeError(f"optimizer_step in the middle of a gradient accumulation ({self._acc_n} micro-batches folded, none marked last); "
+                               "finish it with a forward_backward(last_micro_batch=True) or drop it with reset_accumulation()")
         if self._reduced:
             self._reduced = False
             self.wait_gradients()         # the current stream waits for the slices' reductions
@@ -389,7 +413,6 @@ class Trainer:
         scale *= self._micro_scale
         self._micro_scale = 1.0
         self.step += 1
-        self.global_step += 1
         stream = torch.cuda.current_stream(self.device).cuda_stream
         p = lambda a: C.c_void_p(a.data_ptr()) if a is not None else None
         with torch.cuda.device(self.device):
