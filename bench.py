@@ -204,6 +204,8 @@ def main():
                     help="after the timed region, also decode each rank's latents with the native VAE (SDXL-VAE geometry, random-init "
                          "weights) and report it beside the headline line ('with_vae'); never part of 'value'")
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of the GEMM classes")
+    ap.add_argument("--extra-classes", default="", help="comma-separated non-MFMA kernel classes (cross_row, dwconv_gelu, layernorm, embed, tail, update) to time on the "
+                                                        "untimed profiling pass as well; reported under 'other_classes' (A/B tooling)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-device", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -258,6 +260,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     gemm_classes = ("gemm_qkv", "gemm_up", "gemm_down", "attention")
+    extra_classes = tuple(c for c in args.extra_classes.split(",") if c)
     for _ in range(args.warmup):
         out = one_step()
     fence()
@@ -266,9 +269,10 @@ def main():
     warm_prof = {}
     dom_cls = "gemm_down"
     if not args.no_profile:
-        model.set_profile(gemm_classes)
+        model.set_profile(gemm_classes + extra_classes)
         out = one_step()
         fence()
+        other_prof = {c: model.get_profile(c) for c in extra_classes}
         warm_prof = {c: model.get_profile(c) for c in gemm_classes}
         warm_prof = {c: v for c, v in warm_prof.items() if v[1] > 0}       # (no attention launches: it runs inside the QKV kernel)
         dom_cls = max(warm_prof, key=lambda c: warm_prof[c][0])
@@ -376,6 +380,8 @@ def main():
                         + ("; gemm_qkv = QKV projection + the whole self-attention in one kernel per layer (EPI_QKV_ATTN): its flops are the sum" if fused_att else ""),
                 "mfma_aggregate_tflops": tot_f / tot_t / 1e12,
             }
+        if prof and extra_classes:
+            line["other_classes"] = {c: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for c, v in other_prof.items()}
         if vae_info:
             line["with_vae"] = vae_info
         if world == 1 and not args.no_cpu_baseline:

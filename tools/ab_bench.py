@@ -37,5 +37,6 @@ for rnd in range(a.rounds):
             print(f"{name}: FAILED rc={r.returncode} {r.stderr[-300:]}", flush=True)
             continue
         d = json.loads(line)
-        cls = d.get("roofline", {}).get("all_mfma_classes", {})
+        cls = dict(d.get("roofline", {}).get("all_mfma_classes", {}))
+        cls.update(d.get("other_classes", {}))
         print(f"{name:>10}: {d['value']:8.3f} img/s  {d['ms_per_step']:8.2f} ms | " + " | ".join(f"{c} {v['avg_ms'] * 1e3:.1f}" for c, v in cls.items()), flush=True)

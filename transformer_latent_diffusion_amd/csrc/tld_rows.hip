@@ -1508,8 +1508,14 @@ __global__ __launch_bounds__(320, 4) void dwconv_gelu_stream_kernel(const bf16* 
             R[k][1] = f32x2{(float)v[2], (float)v[3]};
         }
     };
+    // output addresses as running pointers, one add per image row (round 6: `row * C + c0` and the scale index rebuilt per output column were ~20 integer
+    // instructions -- 64-bit multiplies among them -- of the ~90 per column of this VALU-bound loop)
+    // (32-bit byte offsets from the uniform bases: the engine keeps max_batch x tokens x 4 d x 2 B below 4 GiB, tld_engine_create)
     const size_t orow0 = (size_t)b * g * g + j0 + 2 * cg;
-    auto emit = [&](const f32x2 (&U)[4][2], const f32x2 (&M)[4][2], const f32x2 (&D)[4][2], int y) {
+    unsigned ooff = (unsigned)((orow0 * C + c0) * (F8OUT ? 1 : 2));                       // this lane's output column 2 cg of image row y, bytes
+    unsigned soff = F8OUT ? (unsigned)mx8_scale_index(c0, orow0, (size_t)batch * g * g) : 0u;
+    const unsigned ostride = (unsigned)g * (unsigned)C * (F8OUT ? 1u : 2u);               // bytes per image row
+    auto emit = [&](const f32x2 (&U)[4][2], const f32x2 (&M)[4][2], const f32x2 (&D)[4][2]) {
 #pragma unroll
         for (int oc = 0; oc < 2; ++oc) {                     // output column 2 cg + oc: window columns oc .. oc + 2
             f32x2 a[2] = {bs[0], bs[1]};
@@ -1524,16 +1530,17 @@ __global__ __launch_bounds__(320, 4) void dwconv_gelu_stream_kernel(const bf16* 
             a[0] = gelu_erf_fast2_half(a[0]); a[1] = gelu_erf_fast2_half(a[1]);
             bf16x4 o;
             o[0] = (bf16)a[0][0]; o[1] = (bf16)a[0][1]; o[2] = (bf16)a[1][0]; o[3] = (bf16)a[1][1];
-            const size_t row = orow0 + (size_t)y * g + oc;
             if constexpr (F8OUT) {
                 int e8;
                 const unsigned pk = mx8_pack4((float)o[0], (float)o[1], (float)o[2], (float)o[3], &e8);
-                *reinterpret_cast<unsigned*>(out8 + row * C + c0) = pk;
-                if ((cq & 7) == 0) scale8[mx8_scale_index(c0, row, (size_t)batch * g * g)] = (uint8_t)e8;
+                *reinterpret_cast<unsigned*>(out8 + ooff + (unsigned)(oc * C)) = pk;
+                if ((cq & 7) == 0) scale8[soff + oc * 4] = (uint8_t)e8;
             } else {
-                *reinterpret_cast<bf16x4*>(out + row * C + c0) = o;
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(out) + ooff + (unsigned)(oc * C * 2)) = o;
             }
         }
+        ooff += ostride;
+        if constexpr (F8OUT) soff += (unsigned)g * 4u;
     };
     zero_row(R0);                                            // image row -1
     __builtin_amdgcn_s_barrier();                            // B_0: rows 0, 1 landed
@@ -1542,7 +1549,7 @@ __global__ __launch_bounds__(320, 4) void dwconv_gelu_stream_kernel(const bf16* 
     auto step = [&](f32x2 (&U)[4][2], f32x2 (&M)[4][2], f32x2 (&D)[4][2], int y) {
         if (y > 0) __builtin_amdgcn_s_barrier();             // B_y
         if (y + 1 < g) read_row(y + 1, D); else zero_row(D);
-        emit(U, M, D, y);
+        emit(U, M, D);
     };
     int y = 0;
     for (; y + 3 <= g; y += 3) {
