@@ -35,6 +35,29 @@ def held(err, contract, regression, what=""):
     assert err <= regression, f"regression: {what} rel-rms {err:.3e} is inside the contract tolerance {contract:.1e} but above the regression bound {regression:.1e}"
 
 
+# Per-case regression bounds (round 6): the 25-shape sweep, the random-input and per-step sampler checks and the fallback / low-latency shape tests used to
+# assert the contract tolerance only.  tests/golden/regression_bounds.json holds, per case key, ~1.5 x the error this build measured on an MI355X (the engine is
+# bit-reproducible, so the measured value does not move between boxes); tools/parity_bounds.py regenerates it from a recording run
+# (TLD_PARITY_RECORD=<file> pytest -m gpu) and writes the table of measured values, profiles/r06_parity_report.md.
+def _load_bounds():
+    import json, os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regression_bounds.json")
+    return json.load(open(path)) if os.path.exists(path) else {}
+
+
+_BOUNDS = _load_bounds()
+
+
+def held_key(err, contract, key, default_regression=None):
+    """held() with the regression bound looked up by case key (default: the contract tolerance itself when the case has no recorded bound yet)."""
+    import json, os
+    rec = os.environ.get("TLD_PARITY_RECORD")
+    if rec:
+        with open(rec, "a") as f:
+            f.write(json.dumps({"key": key, "err": float(err), "contract": contract}) + "\n")
+    held(err, contract, _BOUNDS.get(key, default_regression if default_regression is not None else contract), key)
+
+
 def _dev():
     assert torch.cuda.is_available(), "GPU tests need a HIP device"
     return torch.device("cuda:0")
@@ -140,8 +163,8 @@ def test_forward_vs_golden_config_sweep(tag):
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     out = m(_t(g[f"{tag}_x"]), _t(g[f"{tag}_sigma"]), _t(g[f"{tag}_label"])).cpu().numpy()
     assert out.shape == g[f"{tag}_x0"].shape
-    r = rel_rms(out, g[f"{tag}_x0"])
-    assert np.isfinite(out).all() and r <= FWD_TOL, (tag, r)
+    assert np.isfinite(out).all()
+    held_key(rel_rms(out, g[f"{tag}_x0"]), FWD_TOL, f"g16/{tag}", FWD_REG)
     # a larger batch of the same rows (other tile / round counts of every GEMM) reproduces them bit for bit
     rep = 9
     big = m(_t(np.tile(g[f"{tag}_x"], (rep, 1, 1, 1))), _t(np.tile(g[f"{tag}_sigma"], (rep, 1))), _t(np.tile(g[f"{tag}_label"], (rep, 1)))).cpu().numpy()
@@ -160,7 +183,7 @@ def test_forward_vs_oracle_random_inputs():
         lab = (rng.standard_normal((B, 768)) * 0.5).astype(np.float32)
         lab[0] = 0.0                                   # the "uncond" all-zero label row
         out = m(_t(x), _t(s), _t(lab)).cpu().numpy()
-        assert rel_rms(out, ora(x, s, lab)) <= FWD_TOL
+        held_key(rel_rms(out, ora(x, s, lab)), FWD_TOL, f"oracle_random/B{B}", FWD_REG)
 
 
 @pytest.mark.parametrize("tag,plus", [("dpm", True), ("ddim", False)])
@@ -175,9 +198,9 @@ def test_g2_sampler_vs_golden(tag, plus):
                                          use_ddpm_plus=plus, trace=True)
     tx0, txt = tx0.cpu().numpy(), txt.cpu().numpy()
     n = int(g["n_iter"])
-    for i in range(n - 1):
-        assert rel_rms(tx0[i], g[f"{tag}_x0"][i]) <= TRAJ_TOL, ("x0", i, rel_rms(tx0[i], g[f"{tag}_x0"][i]))
-        assert rel_rms(txt[i], g[f"{tag}_xt"][i + 1]) <= TRAJ_TOL, ("xt", i)
+    # every step's CFG-combined prediction and updated latent against the reference's own trace (the worst step carries the bound)
+    held_key(max(rel_rms(tx0[i], g[f"{tag}_x0"][i]) for i in range(n - 1)), TRAJ_TOL, f"g2/{tag}/x0_worst_step", TRAJ_REG)
+    held_key(max(rel_rms(txt[i], g[f"{tag}_xt"][i + 1]) for i in range(n - 1)), TRAJ_TOL, f"g2/{tag}/xt_worst_step", TRAJ_REG)
     held(rel_rms(lat.cpu().numpy(), g[f"{tag}_latent"]), TRAJ_TOL, TRAJ_REG, f"g2 {tag} end latent")
 
 
@@ -376,4 +399,4 @@ def test_fallback_paths_vs_golden(knobs, fixture):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     rel = float([ln for ln in r.stdout.splitlines() if ln.startswith("REL")][-1].split()[1])
-    assert rel <= FWD_TOL, (knobs, rel)
+    held_key(rel, FWD_TOL, "fallback/" + ",".join(f"{k}={v}" for k, v in sorted(knobs.items())) + "/" + fixture, FWD_REG)

@@ -97,7 +97,9 @@ def test_adam_and_ema_kernel_vs_reference_update():
     tr.optimizer_step()
     assert (tr.params.cpu() - w.detach()).abs().max() <= 5e-7
     assert (tr.ema.cpu() - e).abs().max() <= 5e-7
-    assert tr.step == 2 and tr.checkpoint()["global_step"] == 2
+    # Adam's bias-correction count follows the optimizer steps; the checkpoint's global_step counts loader iterations (forward_backward calls,
+    # tld/train.py:162-174) -- none ran here, the gradients were written directly
+    assert tr.step == 2 and tr.checkpoint()["global_step"] == 0
 
 
 @pytest.mark.parametrize("N", [64, 128, 256, 1024, 4096])
@@ -470,7 +472,7 @@ def test_checkpoint_is_reference_format_and_resumes(tmp_path):
     tr3.load_checkpoint({"model_ema": ck["model_ema"], "opt_state": {"state": {}, "param_groups": ck["opt_state"]["param_groups"]}, "global_step": 1000})
     assert tr3.step == 0 and tr3.global_step == 1000 and tr3.checkpoint()["global_step"] == 1000
     tr3.optimizer_step()
-    assert tr3.step == 1 and tr3.global_step == 1001
+    assert tr3.step == 1 and tr3.global_step == 1000           # (the loop counter counts forward_backward calls -- loader iterations -- not optimizer steps)
 
 
 def test_gradient_accumulation_equals_one_large_batch():
