@@ -772,8 +772,10 @@ template <int TPW>      // 32-feature tiles per wave: d = 128 TPW, TPW even
 __global__ __launch_bounds__(256) void embed_mfma_kernel(EmbedParams p, const bf16* __restrict__ wl_hl) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int d = TPW * 128, PD = 16, PP = 144;
-    char* wimg = smem;                                            // [2 planes][d][32 B]: Linear weight rows (hi | lo), 16-B chunk c of row f at c ^ ((f >> 3) & 1)
-    float* cw = reinterpret_cast<float*>(smem + 2 * d * 32);      // [16][16] conv weight (row = output)
+    // (round 6: the Linear weight's split-bf16 rows go from L2 straight into the MFMA operand registers -- lane (l31, hi) of tile t wants the 16 bytes
+    // [plane][feature 32 t + l31][8 hi .. 8 hi + 7], and a wave's 64 lanes read one contiguous KiB -- instead of being copied into a 48 KiB LDS image by every
+    // 32-row workgroup first: the fill was as many bytes as the workgroup's output)
+    float* cw = reinterpret_cast<float*>(smem);                   // [16][16] conv weight (row = output)
     float* red = cw + PD * PD;                                    // [3][4 waves][32 tokens] row partials (sum; centred squares; rounded sum) + [4][32] rounded squares
     float* vec = red + 4 * 4 * 32;                                // [3][d]: Linear bias, LayerNorm(d) weight and bias (read per feature quad by every token)
     char* patch = reinterpret_cast<char*>(vec + 3 * d);           // [4 waves][32 tokens][PP] output transpose
@@ -796,12 +798,12 @@ __global__ __launch_bounds__(256) void embed_mfma_kernel(EmbedParams p, const bf
             xin[k] = xb[((size_t)c * p.S + (ti * p.p + u)) * p.S + (tj * p.p + v)];
         }
     }
-    // (the tables are filled AFTER the patch loads were issued: their latency hides under the fill)
-    for (int i = threadIdx.x; i < 2 * d * 2; i += 256) {          // 16-byte chunks: plane, row, chunk
-        const int plane = i / (d * 2), rem = i - plane * d * 2;
-        const int f = rem >> 1, c = rem & 1;
-        *reinterpret_cast<u32x4*>(wimg + plane * d * 32 + f * 32 + ((c ^ ((f >> 3) & 1)) << 4)) =
-            *reinterpret_cast<const u32x4*>(wl_hl + ((size_t)plane * d + f) * PD + c * 8);
+    bf16x8 whf[TPW], wlf[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int f = 32 * (wid * TPW + t) + l31;
+        whf[t] = *reinterpret_cast<const bf16x8*>(wl_hl + (size_t)f * PD + hi * 8);
+        wlf[t] = *reinterpret_cast<const bf16x8*>(wl_hl + ((size_t)d + f) * PD + hi * 8);
     }
     if (threadIdx.x < PD * PD) cw[threadIdx.x] = p.conv_w[threadIdx.x];
     for (int i = threadIdx.x; i < 3 * d / 4; i += 256) {
@@ -848,10 +850,7 @@ __global__ __launch_bounds__(256) void embed_mfma_kernel(EmbedParams p, const bf
     f32x16 acc[TPW];
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
-        const int f = 32 * (wid * TPW + t) + l31;
-        const int off = f * 32 + ((hi ^ ((f >> 3) & 1)) << 4);
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(wimg + off);
-        const bf16x8 wlo = *reinterpret_cast<const bf16x8*>(wimg + d * 32 + off);
+        const bf16x8 wh = whf[t], wlo = wlf[t];
         f32x16 z;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = 0.f;
@@ -1268,7 +1267,7 @@ void launch_embed(const EmbedParams& p, hipStream_t s) {
 #ifdef TLD_RESID_BF16
     if (p.lin_w_hl && p.pd == 16 && p.C * p.p * p.p == 16 && p.d % 256 == 0 && p.d <= 1024) {       // matrix-pipe form
         const int rows = p.batch * p.ntok;
-        const int lds = 2 * p.d * 32 + 16 * 16 * 4 + 4 * 4 * 32 * 4 + 3 * p.d * 4 + 4 * 32 * 144;
+        const int lds = 16 * 16 * 4 + 4 * 4 * 32 * 4 + 3 * p.d * 4 + 4 * 32 * 144;      // conv weight, row partials, bias / LayerNorm vectors, transpose patches
         dim3 grid((unsigned)((rows + 31) / 32));
 #define TLD_EM(TPW) do { TLD_LDS_OPT_IN((embed_mfma_kernel<TPW>), lds); hipLaunchKernelGGL((embed_mfma_kernel<TPW>), grid, dim3(256), lds, s, p, p.lin_w_hl); } while (0)
         if (p.d == 256) TLD_EM(2); else if (p.d == 512) TLD_EM(4); else if (p.d == 768) TLD_EM(6); else TLD_EM(8);
