@@ -1566,12 +1566,20 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
 namespace {
 // BN = 256 unless that leaves the last round of workgroups mostly empty on 256 CUs; then prefer the widest
 // tile whose workgroup count is a whole number of rounds (192 for the residual epilogue), else 128.
-int choose_bn(long M, long N, int epilogue) {
+int choose_bn(long M, long N, int epilogue, long K) {
     const long ntm = (M + 255) / 256;
     const long blocks256 = ntm * ((N + 255) / 256);
     // (a last round that is at least 85 % full counts as whole: 252 tiles on 256 CUs are not a reason to halve the tile)
     const long rounds256 = (blocks256 + 255) / 256;
-    const bool narrow = (N % 256 != 0) || (blocks256 * 100 < rounds256 * 256 * 85 && blocks256 < 3 * 256);
+    bool narrow = (N % 256 != 0) || (blocks256 * 100 < rounds256 * 256 * 85 && blocks256 < 3 * 256);
+    // Round 6: a partly filled last round is cheap where the half-tile tail applies (gemm256p_kernel, HT_OK epilogues on the ring K loop): when the R
+    // left-over tiles of an XCD's 32 workgroups satisfy 2 R <= 32, two workgroups share each of them and the launch costs q + ~0.6 tile times instead of q + 1.
+    // 256-wide tiles then beat twice as many 128-wide ones (C3's block-0 QKV projection, 16 384 rows x 2304: 576 tiles = 2.25 rounds; 84 us as 1152 tiles of 128).
+    // Results do not depend on the tile width (every output element sees the same K order), so the choice may follow the batch size.
+    if (narrow && N % 256 == 0 && K >= 128 && K % 128 == 0 && (epilogue == EPI_F32 || epilogue == EPI_QKV || epilogue == EPI_QKV_LN || epilogue == EPI_BIAS_BF16) && blocks256 >= 256) {
+        const long per_xcd = blocks256 / 8, R = per_xcd % 32;
+        if (blocks256 % 8 == 0 && R > 0 && 2 * R <= 32) narrow = false;
+    }
     int bn = narrow ? 128 : 256;
     if (narrow && epilogue == EPI_BIAS_RESID && N % 192 == 0 && (ntm * (N / 192)) % 256 == 0) bn = 192;
     // down projection at the bench size: 256 x 384 tiles make N = 768 ONE round of 256 workgroups (176 -> 155 us);
@@ -1603,7 +1611,7 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
 #else
     const GemmParams& p = p_in;
 #endif
-    int bn = choose_bn(p.M, p.N, epilogue);
+    int bn = choose_bn(p.M, p.N, epilogue, p.K);
     if (p.conv) {           // 256-wide tiles when the width allows and they fill the chip, else 128
         const long ntm = (p.M + 255) / 256;
         bn = (p.N % 256 == 0 && ntm * (p.N / 256) >= 192) ? 256 : 128;
