@@ -115,7 +115,7 @@ struct G256P : G256<BN> {
 template <int BN, int EPI, bool F8 = false, bool CONV = false, bool RING = false, bool TN = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks) {
     using G = G256P<BN>;
-    static_assert(!RING || (BN == 256 && !F8), "the half-tile ring exists for bf16 256 x 256 tiles");
+    static_assert(!RING || BN == 256, "the half-tile ring exists for 256 x 256 tiles (bf16, and since round 6 MX-fp8)");
     static_assert(!TN || (BN == 256 && EPI == EPI_F32 && !F8 && !CONV && !RING), "transposed operands: fp32 output, 256 x 256 tiles, two-stage loop");
     using frag_t = std::conditional_t<F8, i32x8, bf16x8>;
     constexpr int ESZ = F8 ? 1 : 2;                                     // operand bytes per element
@@ -390,6 +390,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
     // RING + CONV: output pixel (y << 16 | x) and first source pixel of the sample for the four A rows this lane brings in per K-tile; the
     // A offsets are rebuilt from them whenever the stream moves on to the next of the nine taps (ring_conv_tap)
     unsigned rcpix[RING && CONV ? 4 : 1], rcbase[RING && CONV ? 4 : 1];
+    int sc_m0 = 0, sc_n0 = 0;                                 // RING + F8: tile whose half-tiles are being staged (block-scale strips travel with B0)
     auto ring_conv_tap = [&](int tap) {
         if constexpr (RING && CONV) {
             const int ky = tap / 3;
@@ -443,10 +444,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             ring_conv_tap(0);
         } else
         if constexpr (RING) {
+            sc_m0 = tm0; sc_n0 = tn0;
             int ln = lane;
             asm volatile("" : "+v"(ln));
             unsigned wgrp = 0;
-            if constexpr (EPI == EPI_F32 || EPI == EPI_BIAS_BF16) {
+            if constexpr (!F8 && (EPI == EPI_F32 || EPI == EPI_BIAS_BF16)) {
                 if (p.w_batch_rows) wgrp = (unsigned)(tm0 / p.w_batch_rows) * p.w_batch_stride_bytes;
             }
 #pragma unroll
@@ -457,10 +459,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     const unsigned c16 = (unsigned)(((ln & 7) ^ ((r >> 1) & 7)) * 16);
                     int ga = tm0 + (r >> 6) * 128 + h * 64 + (r & 63);
                     ga = ga < p.M ? ga : p.M - 1;
-                    unsigned va = __umul24((unsigned)ga, (unsigned)(p.lda * 2)) + c16;
+                    unsigned va = __umul24((unsigned)ga, (unsigned)(p.lda * ESZ)) + c16;
                     int gb = tn0 + (r >> 5) * 64 + h * 32 + (r & 31);
                     gb = gb < p.N ? gb : p.N - 1;
-                    unsigned vb = __umul24((unsigned)gb, (unsigned)(p.ldw * 2)) + c16 + wgrp;
+                    unsigned vb = __umul24((unsigned)gb, (unsigned)(p.ldw * ESZ)) + c16 + wgrp;
                     asm volatile("" : "+v"(va), "+v"(vb));
                     rvA[h * 2 + q2] = va;
                     rvB[h * 2 + q2] = vb;
@@ -486,6 +488,18 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             asm volatile("" : "+v"(o0), "+v"(o1));   // (keeps the zero-extension next to the load: saddr + 32-bit voffset form)
             __builtin_amdgcn_global_load_lds((gptr_t)(base + o0), (lptr_t)dst, 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)(base + o1), (lptr_t)(dst + 1024), 16, 0, 0);
+            if constexpr (F8 && i == 0) {
+                // MX block scales of K-tile tk (4 bytes per row and K-tile, [K/128][rows][4] in memory: a tile's strip is one contiguous KiB per operand) travel
+                // with the K-tile's FIRST stream element, one quarter strip (64 rows = 16 lanes x 16 B) per wave -- waves 0-3 the A strip, 4-7 the W strip -- so that
+                // every wave issues the same number of VMEM operations per K-tile (the counted waits below: three half-tiles + this piece in flight = vmcnt(7))
+                const bool sa = wid < 4;
+                const int rows = sa ? p.M : p.N;
+                int r = (sa ? sc_m0 : sc_n0) + (wid & 3) * 64 + (lane & 15) * 4;
+                r = r + 3 < rows ? r : rows - 4;                       // (rows % 4 == 0: lanes of valid rows never clamp)
+                const uint8_t* src = (sa ? p.a_scale : p.w_scale) + ((size_t)tk * rows + r) * 4;
+                char* sdst = smem + SC_OFF + (slot >> 2) * 2048 + (sa ? 0 : 1024) + (wid & 3) * 256;
+                if (lane < 16) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)sdst, 16, 0, 0);
+            }
         }
     };
 
@@ -701,19 +715,26 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
             const int grp = wid >> 2;
             const int nj = nk >> 1;
             const bool xt = has_next && !NOXT;
+            // MX-fp8 (round 6): the same ring -- a 128-byte row is 128 K-elements, so half-tiles, slots, swizzle and the stream are unchanged; a k-slice of 64 elements is
+            // TWO of the 16-byte pieces the bf16 loop reads per (row, k-slice) (pieces 2 s and 2 s + 1 = the operand's lower / upper four registers), a phase is 4
+            // v_mfma_scale_f32_32x32x64_f8f6f4 instead of 8 bf16 MFMAs (same 256 matrix cycles), and one quarter strip of block scales per wave rides with every
+            // K-tile's B0 (ring_stage): one more VMEM operation in flight at the counted waits.
+            constexpr int RW = F8 ? 7 : 6;
             if (it == 0 || NOXT) {
                 aux_dma();
                 ring_offsets(m0, n0);
                 ring_stage(I0{}, 0, 0); ring_stage(I1{}, 0, 1); ring_stage(I2{}, 0, 2); ring_stage(I3{}, 0, 3);
                 ring_stage(I0{}, 1, 4); ring_stage(I1{}, 1, 5); ring_stage(I2{}, 1, 6);
-                wait_vmcnt<6>();                   // K-tile 0 (and the side tables) landed: own pieces ...
+                wait_vmcnt<RW>();                  // K-tile 0 (and the side tables) landed: own pieces ...
                 __builtin_amdgcn_s_barrier();      // ... everybody's
             } else {
                 __builtin_amdgcn_s_barrier();      // every wave is done with its epilogue scratch (slots 4-7)
                 aux_dma();
                 ring_stage(I0{}, 1, 4); ring_stage(I1{}, 1, 5); ring_stage(I2{}, 1, 6);
             }
-            frag_t fa[2][4], fb0[4], fb1[4];
+            using piece_t = std::conditional_t<F8, u32x4, bf16x8>;      // one ds_read_b128 of a fragment row
+            piece_t fa[2][4], fb0[4], fb1[4];
+            int rsa[2][2], rsb[2];                                       // F8: this K-tile's raw scale dwords of the lane's rows (A: [quadrant row][32-row tile], B: [quadrant column])
             // fragment read addresses: one register per (operand, k-slice) -- byte offset of (row, chunk (2 ks + hi) ^ swizzle) inside a
             // half-tile image; the slot and the A row-block are immediates, and the registers flip between the two K-tiles' slot groups
             // (bit 16) as the loop goes: no per-read address arithmetic
@@ -729,7 +750,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     asm volatile("" : "+v"(ra[ks]), "+v"(rb[ks]));
                 }
             }
-            auto rd = [&](unsigned a, int imm) { return *reinterpret_cast<const frag_t*>(smem + a + imm); };
+            auto rd = [&](unsigned a, int imm) { return *reinterpret_cast<const piece_t*>(smem + a + imm); };
             if (grp) __builtin_amdgcn_s_barrier(); // stagger in
             auto iter = [&](int j, auto lastc) {
                 constexpr bool last = decltype(lastc)::value;
@@ -738,6 +759,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     constexpr int q = (ph - 1) & 3;
                     // ---- R half   (slots of this K-tile: B0 A0 B1 A1 at 0, HT, 2 HT, 3 HT from the current slot group)
                     if constexpr (q == 0) {
+                        if constexpr (F8) {        // issued BEFORE the B0 reads: retired with them (lgkmcnt(8) below), so the strip is free when B0's slot is
+                            const char* sc = smem + SC_OFF + ((ph - 1) >> 2) * 2048;
+#pragma unroll
+                            for (int qa2 = 0; qa2 < 2; ++qa2)
+#pragma unroll
+                                for (int ii = 0; ii < 2; ++ii) rsa[qa2][ii] = *reinterpret_cast<const int*>(sc + (wm * 128 + qa2 * 64 + ii * 32 + l31) * 4);
+#pragma unroll
+                            for (int qb2 = 0; qb2 < 2; ++qb2) rsb[qb2] = *reinterpret_cast<const int*>(sc + 1024 + (wn * 64 + qb2 * 32 + l31) * 4);
+                        }
 #pragma unroll
                         for (int ks = 0; ks < 4; ++ks) fb0[ks] = rd(rb[ks], 0);
                         __builtin_amdgcn_sched_barrier(0);
@@ -775,9 +805,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                         }
                     }
                     if constexpr (ph == 4) {
-                        if (last && !xt) wait_vmcnt<0>(); else wait_vmcnt<6>();
+                        if (last && !xt) wait_vmcnt<0>(); else wait_vmcnt<RW>();
                     }
-                    if constexpr (ph == 8 && !last) wait_vmcnt<6>();
+                    if constexpr (ph == 8 && !last) wait_vmcnt<RW>();
                     if constexpr (q == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // B0 reads retired: its slot is restaged next phase
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
@@ -787,16 +817,43 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p, int nblocks
                     // ---- M half: one C quadrant x K = 64
                     constexpr int qa = (q >= 2) ? 1 : 0, qb = (q == 1 || q == 2) ? 1 : 0;
                     if (!(hmode && ht_qa != qa)) {        // (half-tile item: the other quadrant row's MFMAs are not this workgroup's)
+                    if constexpr (F8) {
+                        // half hi of a row uses scale bytes hi (k 0-31 of slice 0 ... see load_frags) and 2 + hi: shift once, op_sel picks byte 0 / 2 per k-slice
+                        const int sb = (qb ? rsb[1] : rsb[0]) >> (8 * hi);
+                        const int sa0 = rsa[qa][0] >> (8 * hi), sa1 = rsa[qa][1] >> (8 * hi);
+                        auto cat = [](const piece_t& lo, const piece_t& hi4) {
+                            return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi4[0], (int)hi4[1], (int)hi4[2], (int)hi4[3]};
+                        };
+                        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                        for (int sl = 0; sl < 2; ++sl) {
+                            const i32x8 bo = qb ? cat(fb1[2 * sl], fb1[2 * sl + 1]) : cat(fb0[2 * sl], fb0[2 * sl + 1]);
+#pragma unroll
+                            for (int ii = 0; ii < 2; ++ii) {
+                                const i32x8 ao = cat(fa[ii][2 * sl], fa[ii][2 * sl + 1]);
+                                const int sa = ii ? sa1 : sa0;
+                                if (sl == 0) {
+                                    if constexpr (SW) acc[qa * 2 + ii][qb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bo, ao, acc[qa * 2 + ii][qb], 0, 0, 0, sb, 0, sa);
+                                    else acc[qa * 2 + ii][qb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[qa * 2 + ii][qb], 0, 0, 0, sa, 0, sb);
+                                } else {
+                                    if constexpr (SW) acc[qa * 2 + ii][qb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(bo, ao, acc[qa * 2 + ii][qb], 0, 0, 2, sb, 2, sa);
+                                    else acc[qa * 2 + ii][qb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ao, bo, acc[qa * 2 + ii][qb], 0, 0, 2, sa, 2, sb);
+                                }
+                            }
+                        }
+                        __builtin_amdgcn_s_setprio(0);
+                    } else {
                     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                         for (int ii = 0; ii < 2; ++ii) {
-                            const frag_t& bf = qb ? fb1[ks] : fb0[ks];
+                            const piece_t& bf = qb ? fb1[ks] : fb0[ks];
                             if constexpr (SW) acc[qa * 2 + ii][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, fa[ii][ks], acc[qa * 2 + ii][qb], 0, 0, 0);
                             else acc[qa * 2 + ii][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ii][ks], bf, acc[qa * 2 + ii][qb], 0, 0, 0);
                         }
                     __builtin_amdgcn_s_setprio(0);
+                    }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
@@ -1486,8 +1543,10 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
     // four groups for the up-projection (neutral), two / four groups for the down-projection (A is the 201 MB
     // operand there: neutral / 175 -> 195 us).  Large launches only: every XCD cell needs workgroups of its own.
     // half-tile ring K loop (256 x 256 tiles, bf16, no conv): an iteration is two K-tiles, so K must be a multiple of 128
-    const bool use_ring = nsplit > 1 ? false : p.conv ? (9 * (p.cv_cin >> 6)) % 2 == 0 : (p.K >= 128 && p.K % 128 == 0);      // (conv: K = 9 cv_cin, an even number of 64-wide K-tiles)
+    const bool use_ring = nsplit > 1 ? false : p.conv ? (9 * (p.cv_cin >> 6)) % 2 == 0 : p.f8 ? (p.K >= 256 && p.K % 256 == 0)
+                                                                                        : (p.K >= 128 && p.K % 128 == 0);      // (an even number of 128-byte K-tiles; conv: K = 9 cv_cin)
     (void)use_ring;
+    static const bool f8_ring = !(getenv("TLD_F8_RING") && atoi(getenv("TLD_F8_RING")) == 0);        // A/B hook: 0 = the two-stage loop under the fp8 GEMMs (round 2 - 5)
     GemmParams pg = p;
     static const bool half_tail = !(getenv("TLD_GEMM_HALFTAIL") && atoi(getenv("TLD_GEMM_HALFTAIL")) == 0);     // test hook: tests/test_gpu_parity.py holds the row-split tail bitwise equal to the unsplit run
     pg.half_tail = half_tail ? 1 : 0;
@@ -1510,9 +1569,10 @@ void launch256p(const GemmParams& p, int epilogue, hipStream_t s) {
                             : ((E) == EPI_QKV_ATTN ? G::ATTN_LDS                                      \
                             : ((E) == EPI_QKV_LN ? G::QKVLN_LDS                                        \
                             : ((E) == EPI_BIAS_BF16 && BN != 384 ? G::PLAINLN_LDS : G::LDS_BYTES))));  /* (384-wide: 160 KB of stages, no LayerNorm-3 fold) */ \
-        constexpr bool ring_ok = TLD_KLOOP_RING && BN == 256 && !(F8);                                \
+        /* (fp8 + residual-add epilogue on the ring: 172 spilled registers, also with the lane-derived values re-materialised -- that one stays on the two-stage loop) */ \
+        constexpr bool ring_ok = TLD_KLOOP_RING && BN == 256 && !((F8) && ((CV) || (E) == EPI_BIAS_RESID)); \
         if constexpr (ring_ok) {                                                                      \
-            if (use_ring) TLD_L256P_LAUNCH(E, F8, CV, true); else TLD_L256P_LAUNCH(E, F8, CV, false); \
+            if (use_ring && (!(F8) || f8_ring)) TLD_L256P_LAUNCH(E, F8, CV, true); else TLD_L256P_LAUNCH(E, F8, CV, false); \
         } else {                                                                                      \
             TLD_L256P_LAUNCH(E, F8, CV, false);                                                       \
         }                                                                                             \
@@ -1618,7 +1678,10 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
     }
     if (p.f8) {             // the fp8 kernel is instantiated for 256 / 128 (all epilogues) and 192 (residual add: N = 768 in whole rounds)
         const long ntm = (p.M + 255) / 256;
-        if (epilogue == EPI_BIAS_RESID && p.N % 192 == 0 && ((ntm * (p.N / 192)) % 256 == 0 || p.N % 256 != 0)) bn = 192;
+        // (round 6: where 256-wide tiles fill whole rounds they beat the 192-wide ones -- the down projection at C4, 65 536 rows: 768 tiles in 3 rounds against 1024 in 4,
+        // 207.7 -> 174.8 us same-box; results do not depend on the tile width, the LayerNorm-1 partial sums are not taken in fp8 mode)
+        if (epilogue == EPI_BIAS_RESID && p.N % 256 == 0 && (ntm * (p.N / 256)) % 256 == 0) bn = 256;
+        else if (epilogue == EPI_BIAS_RESID && p.N % 192 == 0 && ((ntm * (p.N / 192)) % 256 == 0 || p.N % 256 != 0)) bn = 192;
         else bn = (p.N % 256 == 0) ? 256 : 128;
     }
     if (epilogue == EPI_F32 && p.ksplit > 1 && !p.f8 && !p.conv) bn = 128;     // split-K: the narrow tile has no ring instantiation to fall into and gives the most work items
