@@ -177,6 +177,72 @@ def cpu_baseline(cfg, sd, budget_s=20.0, S=32):
     return res
 
 
+class PowerPoller:
+    """Socket power and shader clock of the bench device from hwmon sysfs while one step of the workload runs (outside the timed region, see main): the part holds a power cap
+    by lowering its clock, so the MFMA peak the kernels can reach is the guide's 2.5 PFLOP/s scaled by sclk / 2400 MHz.
+    Best effort: absent or unreadable files give no 'power' object in the JSON line."""
+
+    def __init__(self, dev_index, period=0.25):
+        import glob
+        import threading
+        self.files = None
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+        except Exception:
+            pass
+        cands = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            f = {k: os.path.join(d, k) for k in ("power1_average", "power1_input", "freq1_input", "power1_cap") if os.path.exists(os.path.join(d, k))}
+            if ("power1_average" in f or "power1_input" in f) and "freq1_input" in f:
+                pci = os.path.basename(os.path.realpath(os.path.join(d, "..", "..")))
+                cands.append((pci, f))
+        match = [c for c in cands if want and c[0].startswith(want)]
+        self.cands = match if match else cands          # (no PCI match: keep all, the busiest one is ours -- one GPU is visible to this process)
+        self.rows = [[] for _ in self.cands]
+        self.stop = False
+        self.period = period
+        self.thread = threading.Thread(target=self._run, daemon=True) if self.cands else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as h:
+                return int(h.read().strip())
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self.stop:
+            for i, (_, f) in enumerate(self.cands):
+                p = self._read(f.get("power1_average", f.get("power1_input")))
+                c = self._read(f["freq1_input"])
+                if p is not None and c is not None:
+                    self.rows[i].append((p / 1e6, c / 1e6))
+            time.sleep(self.period)
+
+    def start(self):
+        if self.thread:
+            self.thread.start()
+
+    def finish(self):
+        if not self.thread:
+            return None
+        self.stop = True
+        self.thread.join(timeout=1.0)
+        best = max(range(len(self.cands)), key=lambda i: sum(r[0] for r in self.rows[i]) / max(len(self.rows[i]), 1))
+        rows = self.rows[best]
+        if len(rows) < 2:
+            return None
+        pw = sorted(r[0] for r in rows)
+        ck = sorted(r[1] for r in rows)
+        cap = self._read(self.cands[best][1]["power1_cap"]) if "power1_cap" in self.cands[best][1] else None
+        return {"avg_w": sum(pw) / len(pw), "median_w": pw[len(pw) // 2], "cap_w": cap / 1e6 if cap else None,
+                "sclk_mhz_median": ck[len(ck) // 2], "sclk_mhz_min": ck[0], "sclk_mhz_max": ck[-1], "samples": len(rows),
+                "source": f"hwmon sysfs of {self.cands[best][0]}, sampled every {self.period:.2f} s over ~1 s of extra (untimed) steps of the same workload"}
+
+
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` (N > 1) without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
     import socket
@@ -206,6 +272,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip HIP-event timing of the GEMM classes")
     ap.add_argument("--extra-classes", default="", help="comma-separated non-MFMA kernel classes (cross_row, dwconv_gelu, layernorm, embed, tail, update) to time on the "
                                                         "untimed profiling pass as well; reported under 'other_classes' (A/B tooling)")
+    ap.add_argument("--no-power", action="store_true", help="do not poll hwmon power / clock during the timed region")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--same-device", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (needs --backend gloo)")
@@ -289,6 +356,18 @@ def main():
     marks[args.steps].record()
     fence()
     dt = time.perf_counter() - t0
+    # socket power and shader clock of the same workload, on a few MORE steps after the timed region: a hwmon read stalls the device for milliseconds (four reads per
+    # second inside the timed region cost 2.5 % of the images/s, a hundred 4-7 %, and at 50 reads per second the reading itself drops from 1350 to 1135 W: same-box
+    # A/B in profiles/r06_power_probe.txt), so the timed steps run unobserved and the observed ones are sampled five times a second
+    power = None
+    if rank == 0 and world == 1 and not args.no_power:       # (one rank only: a step of the sharded path ends in a collective)
+        poller = PowerPoller(dev.index, period=0.2)
+        poller.start()
+        t_obs = time.perf_counter()
+        while time.perf_counter() - t_obs < 0.9:
+            one_step()
+            torch.cuda.synchronize(dev)
+        power = poller.finish()
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     assert torch.isfinite(out).all()
@@ -380,6 +459,12 @@ def main():
                         + ("; gemm_qkv = QKV projection + the whole self-attention in one kernel per layer (EPI_QKV_ATTN): its flops are the sum" if fused_att else ""),
                 "mfma_aggregate_tflops": tot_f / tot_t / 1e12,
             }
+            if power and power.get("sclk_mhz_median"):
+                # the same kernel against the MFMA rate of the clock the part actually held under its power cap (peak is quoted at 2400 MHz)
+                line["roofline"]["peak_at_sustained_clock"] = peak * power["sclk_mhz_median"] / 2400.0
+                line["roofline"]["frac_at_sustained_clock"] = ach / (peak * power["sclk_mhz_median"] / 2400.0)
+        if power:
+            line["power"] = power
         if prof and extra_classes:
             line["other_classes"] = {c: {"avg_ms": v[0] / max(v[1], 1), "launches": v[1]} for c, v in other_prof.items()}
         if vae_info:
