@@ -74,12 +74,16 @@ TLD_API int tld_engine_finalize_weights(tld_engine* e);
  * Not in the reference (its model_dtype is fp32 / fp16 / bf16, tld/configs.py:33-37): BASELINE config C4. */
 TLD_API int tld_engine_set_gemm_dtype(tld_engine* e, int32_t dtype);
 
-/* Low-latency capacity class (round 5; no counterpart in the reference, whose serving path -- tld/app.py:48-65 -- runs one prompt per call on whatever
- * kernels PyTorch picks): for engines of at most 4096 token rows (max_batch x tokens; e.g. 8 images = 16 CFG-doubled samples at 256 px) the MLP down projection of
- * every block runs as four K-splits + a finishing kernel, which takes a one-image step from 1.7 ms towards 1.2 ms.  Results differ from the default
- * class in the fp32 summation order of that product (same tolerances against the reference); inside a class they are bit-identical across batch sizes.
+/* Low-latency capacity classes (round 5 / 6; no counterpart in the reference, whose serving path -- tld/app.py:48-65 -- runs one prompt per call on whatever
+ * kernels PyTorch picks): the MLP down projection of every block runs as K-splits + a finishing kernel.
+ *   on = 1: four K-splits, engines of at most 4096 token rows (max_batch x tokens; e.g. 8 images = 16 CFG-doubled samples at 256 px)
+ *   on = 2: eight K-splits, engines of at most 1024 token rows (one or two images per CFG call at 256 px -- the one-prompt-per-call pattern)
+ *   on = 0: the default class
+ * A one-image 35-step generate takes 50 ms in the default class, 36 ms in class 1, 33 ms in class 2; at four images class 1 is the faster one.  Results of a class differ from
+ * the default class (and from the other class) in the fp32 summation order of that product (same tolerances against the reference); a class is chosen by the CALLER for the engine,
+ * never by the batch of a call: inside a class results are bit-identical across batch sizes.
  * May be called any time after tld_engine_create; fails (TLD_ERR_INVALID) on larger engines, on widths other than 384 / 768, on hidden widths that do not split
- * into four multiples of 64, and on engines in the MX-fp8 GEMM mode (bf16 operands only; tld_engine_set_gemm_dtype(fp8) likewise refuses an engine of this class). */
+ * into that many multiples of 64, and on engines in the MX-fp8 GEMM mode (bf16 operands only; tld_engine_set_gemm_dtype(fp8) likewise refuses an engine of these classes). */
 TLD_API int tld_engine_set_low_latency(tld_engine* e, int32_t on);
 
 /* Denoiser.forward(x, noise_level, label) -- tld/denoiser.py:116-126 (called at tld/diffusion.py:97-101).

@@ -335,6 +335,29 @@ def test_low_latency_class_vs_golden_and_inside_the_class():
         odd(torch.zeros(1, 4, 32, 32, device=_dev()), torch.full((1, 1), 0.5, device=_dev()), torch.zeros(1, 768, device=_dev()))
 
 
+def test_low_latency_class_2_eight_splits():
+    """Class 2 of Denoiser.set_low_latency (round 6): eight K-splits for engines of at most 1024 token rows -- the one-prompt-per-call pattern (tld/app.py:48-65).  Held against
+    the reference's own forward like class 1, bit-identical across the batch sizes it admits, and refused beyond its capacity."""
+    from transformer_latent_diffusion_amd import Denoiser
+    g = load_golden("g5_100m.npz")
+    cfg = cfg_from_arr(g["cfg"])
+    sd = synth_weights(cfg, g["weight_seed"], g["weight_checksum"])
+    m = Denoiser(**asdict(cfg)).to(_dev()).set_low_latency(2)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    x, s, lab = g["x"][:2], g["sigma"][:2], g["label"][:2]
+    m.reserve(4)                                               # 4 x 256 = 1024 token rows: the class's capacity
+    one = m(_t(x[:1]), _t(s[:1]), _t(lab[:1])).cpu().numpy()
+    out = m(_t(x), _t(s), _t(lab)).cpu().numpy()
+    four = m(_t(np.tile(x, (2, 1, 1, 1))), _t(np.tile(s, (2, 1))), _t(np.tile(lab, (2, 1)))).cpu().numpy()
+    assert np.isfinite(out).all()
+    held(rel_rms(out, g["x0"][:2]), FWD_TOL, FWD_REG, "g5 forward, low-latency class 2")
+    assert np.array_equal(one, out[:1]) and np.array_equal(four[:2], out) and np.array_equal(four[2:], out), "class 2 results depend on the batch size"
+    with pytest.raises(RuntimeError, match="low-latency class"):
+        m(_t(np.tile(x, (3, 1, 1, 1))), _t(np.tile(s, (3, 1))), _t(np.tile(lab, (3, 1))))            # 6 x 256 rows: beyond class 2
+    with pytest.raises(ValueError):
+        m.set_low_latency(3)
+
+
 @pytest.mark.parametrize("tag", ["d384", "n1024_d384", "n64_d768", "mlp2_d768"])
 def test_low_latency_class_on_other_shapes_vs_golden(tag):
     """The low-latency class away from the 100 M shape, against the reference's own forwards (g16): d = 384 (the finishing kernel's 6-columns-per-lane

@@ -138,3 +138,24 @@ def test_fused_dwconv_epilogue_by_position_class(golden_name, batch, tile_rows):
         d = (fused - plain)[:, mask]
         r = float(np.sqrt((d ** 2).mean()) / np.sqrt((plain[:, mask] ** 2).mean()))
         assert r <= FUSED_DW_RMS, (cname, r)
+
+
+# ---- the small-batch form of the fused up-projection (tld_updw.hip: 256 x 128 tiles, 4-wave workgroups, taken while a launch has at most one tile per CU) must be
+# ---- BITWISE the 8-wave kernel -- that is what lets the tile shape follow the batch size.  TLD_UPDW_SMALL is read once per process: the 8-wave run is a subprocess.
+@pytest.mark.parametrize("batch", [1, 3, 5])
+def test_small_batch_up_projection_bitwise_equals_8_wave_kernel(batch, tmp_path):
+    import os
+    import subprocess
+    import sys
+    post, _, _, _, _ = _hidden_stages("g5_100m.npz", batch, {"TLD_FUSE_DWCONV": "1"})
+    assert np.isfinite(post).all() and np.abs(post).max() > 0
+    ref = tmp_path / "hid.npy"
+    code = ("import sys, numpy as np\n"
+            "sys.path.insert(0, 'tests')\n"
+            "import test_gpu_dwconv as t\n"
+            f"post, _, _, _, _ = t._hidden_stages('g5_100m.npz', {batch}, {{'TLD_FUSE_DWCONV': '1'}})\n"
+            f"np.save(r'{ref}', post)\n")
+    env = dict(os.environ, TLD_UPDW_SMALL="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(post, np.load(ref)), "the 256 x 128-tile form of the fused up-projection differs from the 8-wave kernel"

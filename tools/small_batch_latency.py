@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Latency of one 35-step CFG `generate` of the 100 M model at 256 px for small batches, default capacity class against the low-latency class
-(Denoiser.set_low_latency: split-K down projection).  The reference's serving path runs ONE prompt per call (tld/app.py:48-65).
+(Denoiser.set_low_latency: split-K down projection in four K-splits = class 1, 'low-latency', or eight = class 2, 'low-latency-2', one or two images).  The reference's serving path runs ONE prompt per call (tld/app.py:48-65).
     python tools/small_batch_latency.py [--batches 1,2,4,8,16] [--iters 5]"""
 import argparse
 import os
@@ -24,7 +24,7 @@ dev = torch.device("cuda", 0)
 cfg = config_100m(32)
 sd = {k: torch.from_numpy(np.array(v)) for k, v in synth_state_dict(cfg, 5).items()}
 models = {}
-for name, ll in (("default", False), ("low-latency", True)):
+for name, ll in (("default", 0), ("low-latency", 1), ("low-latency-2", 2)):
     m = Denoiser(**asdict(cfg)).to(dev)
     m.load_state_dict(sd)
     m.set_low_latency(ll)
@@ -34,6 +34,8 @@ for B in [int(b) for b in args.batches.split(",")]:
     labels = (torch.randn(B, 768, generator=torch.Generator().manual_seed(12)) * 0.5).to(dev)
     outs, line = {}, []
     for name, m in models.items():
+        if name == "low-latency-2" and 2 * B * 256 > Denoiser.LOW_LATENCY_MAX_ROWS_SINGLE:      # class 2 (eight K-splits): one or two images per call
+            continue
         gen = DiffusionGenerator(m, None, dev, torch.float32)
         run = lambda: gen.generate_latents(labels, n_iter=35, num_imgs=B, class_guidance=6, img_size=32, sharp_f=0.0, bright_f=0.0, exponent=1, seeds=x_T)
         outs[name] = run(); torch.cuda.synchronize()

@@ -121,7 +121,8 @@ struct tld_engine {
     bool share_l0 = true;              // TLD_SHARE_L0=0 disables (A/B testing)
     bool fold_ln1 = true;              // TLD_FOLD_LN1=0: separate LayerNorm-1 kernel (A/B testing)
     bool low_latency = false;          // tld_engine_set_low_latency: capacity class for small batches (round 5) -- the down projection runs as split-K (see run_body)
-    float* splitk = nullptr;           // [kLowLatSplit][max rows][d] fp32 slices of it
+    float* splitk = nullptr;           // [ll_split][max rows][d] fp32 slices of it
+    int ll_split = 0;                  // K-splits of the low-latency down projection (4 or 8, from the engine's capacity: lowlat_split)
     bool fuse_qkv_attn = true;         // 256-token grids with the LayerNorm-1 fold: QKV GEMM + self-attention as ONE kernel per (sample, head) (TLD_FUSE_QKV_ATTN=0: two kernels)
     float2* ln_stats = nullptr;        // [M][kLnSlots] row partial sums of the residual stream (embed / down GEMM -> QKV GEMM)
     bool fold_ln3 = true;              // TLD_FOLD_LN3=0: cross_row writes LN3(x) and the up-projection reads it (A/B testing)
@@ -253,7 +254,11 @@ struct ProfScope {
 
 // block 0's MLP hidden tensors (bf16 [M, hid]; debug only, own buffers: they are mlp_multiplier times a residual-stream stage): "blk0_hid" = after the
 // depthwise conv + GELU on whichever path ran, "blk0_hid_pre" = the up-projection's output where it exists in HBM (the two-kernel path)
-constexpr int kLowLatSplit = 4;             // K-splits of the low-latency down projection
+// K-splits of the low-latency down projection: class 1 = four (engines of at most 4096 token rows), class 2 = eight (at most 1024 token rows: one or two images per CFG call, the
+// one-prompt-per-call pattern).  Round 6: eight splits take a one-image generate from 36.4 to 33.4 ms, but cost 6-8 ms at four or five images (twice the work items of 6 K-steps each
+// no longer fit one round of workgroups, and the finishing kernel reads twice the slices) -- hence two classes, each chosen by the CALLER for the engine and each with its own fp32
+// summation order: inside a class results are bit-identical across batch sizes.
+constexpr int kLowLatMaxRows2 = 1024;
 constexpr int kLowLatMaxRows = 4096;        // capacity of the low-latency class (token rows = max_batch x tokens): beyond it the tiles fill the chip by themselves
 
 int capture_hidden(tld_engine* e, const char* name, const bf16* src, size_t count, hipStream_t s) {
@@ -448,10 +453,10 @@ int run_body(tld_engine* e, const float* x_src, int src_batch, int batch, const 
             // its capacity), never of the batch a call happens to carry: inside a class results stay bit-identical across batch sizes.
             ProfScope ps(e, KC_GEMM_DOWN, s);
             GemmParams g{};
-            g.A = e->hid2; g.lda = e->hid; g.W = Ly.down_w; g.ldw = e->hid; g.M = M; g.N = d; g.K = e->hid / kLowLatSplit; g.ksplit = kLowLatSplit;
+            g.A = e->hid2; g.lda = e->hid; g.W = Ly.down_w; g.ldw = e->hid; g.M = M; g.N = d; g.K = e->hid / e->ll_split; g.ksplit = e->ll_split;
             g.c_f32 = e->splitk; g.ldc = d;
             launch_gemm(g, EPI_F32, s);
-            launch_splitk_resid(e->splitk, kLowLatSplit, (size_t)M * d, Ly.down_b, e->x, (fold1 && l + 1 < e->L) ? e->ln_stats : nullptr, M, d, s);
+            launch_splitk_resid(e->splitk, e->ll_split, (size_t)M * d, Ly.down_b, e->x, (fold1 && l + 1 < e->L) ? e->ln_stats : nullptr, M, d, s);
         } else
         {   // x += hid2 Wdown^T + b
             ProfScope ps(e, KC_GEMM_DOWN, s);
@@ -1031,15 +1036,20 @@ int tld_engine_set_low_latency(tld_engine* e, int32_t on) {
     if (!e) return fail(TLD_ERR_INVALID, "null engine");
     DeviceGuard dg(e->cfg.device_id);
     if (!on) { e->low_latency = false; return TLD_OK; }
+    if (on != 1 && on != 2) return fail(TLD_ERR_INVALID, "low-latency class %d: 0 = off, 1 = four K-splits (engines up to %d token rows), 2 = eight (up to %d)", on, kLowLatMaxRows, kLowLatMaxRows2);
     if (e->fp8)
         return fail(TLD_ERR_INVALID, "low-latency class: bf16 GEMM operands only -- this engine runs MX-fp8 GEMMs (tld_engine_set_gemm_dtype), whose down projection has no split-K form");
     const int64_t rows = (int64_t)e->cfg.max_batch * e->ntok;
-    if (rows > kLowLatMaxRows)
-        return fail(TLD_ERR_INVALID, "low-latency class: engine capacity %lld token rows (max_batch %d x %d tokens) exceeds %d -- at that size the default tiles fill the chip",
-                    (long long)rows, e->cfg.max_batch, e->ntok, kLowLatMaxRows);
-    if (!splitk_resid_supported(e->d) || e->hid % (64 * kLowLatSplit) != 0)
-        return fail(TLD_ERR_INVALID, "low-latency class: needs embed_dim 384 or 768 (got %d) and a hidden width that splits into %d multiples of 64 (got %d)", e->d, kLowLatSplit, e->hid);
-    if (!e->splitk) { if (int rc = dev_alloc(e, &e->splitk, (size_t)kLowLatSplit * rows * e->d)) return rc; }
+    const int max_rows = on == 2 ? kLowLatMaxRows2 : kLowLatMaxRows;
+    if (rows > max_rows)
+        return fail(TLD_ERR_INVALID, "low-latency class %d: engine capacity %lld token rows (max_batch %d x %d tokens) exceeds %d -- at that size %s",
+                    on, (long long)rows, e->cfg.max_batch, e->ntok, max_rows, on == 2 ? "class 1 (four K-splits) is the faster one" : "the default tiles fill the chip");
+    const int split = on == 2 ? 8 : 4;
+    if (!splitk_resid_supported(e->d) || e->hid % (64 * split) != 0)
+        return fail(TLD_ERR_INVALID, "low-latency class: needs embed_dim 384 or 768 (got %d) and a hidden width that splits into %d multiples of 64 (got %d)", e->d, split, e->hid);
+    if (e->splitk && e->ll_split < split) e->splitk = nullptr;      // (a class-1 buffer is too small for eight slices: allocate anew; the old one is released with the engine)
+    if (!e->splitk) { if (int rc = dev_alloc(e, &e->splitk, (size_t)split * rows * e->d)) return rc; }
+    e->ll_split = split;
     e->low_latency = true;
     return TLD_OK;
 }

@@ -1671,6 +1671,12 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
 #else
     const GemmParams& p = p_in;
 #endif
+    if (epilogue == EPI_UP_DWCONV2) {
+        // small batches (one to five images per call): one 256 x 128 tile per workgroup on twice as many CUs finishes sooner than one 256 x 256 tile (17.7 vs 28.6 us at one
+        // image); results are bitwise those of the 8-wave kernel (tld_updw.hip), so the choice may follow the batch size.  TLD_UPDW_SMALL=0: A/B and test hook.
+        static const bool small_on = !(getenv("TLD_UPDW_SMALL") && atoi(getenv("TLD_UPDW_SMALL")) == 0);
+        if (small_on && updw_pp_supported(p) && (long)(p.M / 256) * (p.N / 128) <= device_cu_count()) { launch_updw_pp(p, s); return; }
+    }
     int bn = choose_bn(p.M, p.N, epilogue, p.K);
     if (p.conv) {           // 256-wide tiles when the width allows and they fill the chip, else 128
         const long ntm = (p.M + 255) / 256;

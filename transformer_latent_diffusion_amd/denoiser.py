@@ -56,7 +56,7 @@ class Denoiser:
         self._engine_batch = 0
         self._engine_device = None
         self._gemm_dtype = 0              # 0: bf16 operands; 1: MX-fp8 QKV / MLP GEMMs (set_gemm_dtype)
-        self._low_latency = False         # capacity class for small batches (set_low_latency): split-K down projection
+        self._low_latency = 0             # capacity class for small batches (set_low_latency): 0 default, 1 / 2 = split-K down projection in four / eight splits
         self.training = False
 
     # ---- nn.Module-like surface ------------------------------------------------------------------
@@ -147,7 +147,7 @@ class Denoiser:
             if self._gemm_dtype:
                 _lib.check(L.tld_engine_set_gemm_dtype(h, self._gemm_dtype), "tld_engine_set_gemm_dtype")
             if self._low_latency:
-                _lib.check(L.tld_engine_set_low_latency(h, 1), "tld_engine_set_low_latency")
+                _lib.check(L.tld_engine_set_low_latency(h, int(self._low_latency)), "tld_engine_set_low_latency")
             for k, t in self._state.items():
                 if t.dtype == torch.int64:
                     continue
@@ -173,13 +173,19 @@ class Denoiser:
 
     LOW_LATENCY_MAX_ROWS = 4096          # engine capacity (model batch x tokens) of the low-latency class: kLowLatMaxRows in csrc/tld_engine.hip
 
-    def set_low_latency(self, on: bool = True) -> "Denoiser":
-        """Serve SMALL batches in the low-latency capacity class (``tld_engine_set_low_latency``): the MLP down projection of every block runs as
-        split-K, which cuts a one-image denoise step from ~1.7 ms to ~1.2 ms (the reference's serving pattern is one prompt per call,
-        tld/app.py:48-65).  The class is a property of this model object, not of a call: every engine it builds is in the class, results inside it
-        are bit-identical across batch sizes, and they differ from the default class only in the fp32 summation order of that product.  A batch
-        whose CFG-doubled size x tokens exceeds ``LOW_LATENCY_MAX_ROWS`` raises -- build a second model object for bulk generation."""
-        on = bool(on)
+    LOW_LATENCY_MAX_ROWS_SINGLE = 1024   # ... of class 2 (eight K-splits): kLowLatMaxRows2
+
+    def set_low_latency(self, on=True) -> "Denoiser":
+        """Serve SMALL batches in a low-latency capacity class (``tld_engine_set_low_latency``): the MLP down projection of every block runs as
+        split-K, which cuts a one-image 35-step ``generate`` from ~50 ms to ~36 ms (``True`` / ``1``: four K-splits, up to ``LOW_LATENCY_MAX_ROWS``
+        token rows = 8 images at 256 px) or ~33 ms (``2``: eight K-splits, up to ``LOW_LATENCY_MAX_ROWS_SINGLE`` = one or two images per call --
+        the reference's serving pattern, one prompt per call, tld/app.py:48-65).  A class is a property of this model object, not of a call: every
+        engine it builds is in the class, results inside it are bit-identical across batch sizes, and they differ from the default class (and from
+        the other class) only in the fp32 summation order of that product.  A batch whose CFG-doubled size x tokens exceeds the class's capacity
+        raises -- build a second model object for bulk generation."""
+        on = int(on)
+        if on not in (0, 1, 2):
+            raise ValueError("set_low_latency: False / 0 (default class), True / 1 (four K-splits) or 2 (eight K-splits, one or two images per call)")
         if on != self._low_latency:
             self._drop_engine()
         self._low_latency = on

@@ -135,17 +135,18 @@ class DiffusionTransformer:
     ``tokenizer``: a ``ClipTokenizer`` (clip_tokenizer.py) or the path of CLIP's merges file -- prompts are then tokenised here
     (``clip.tokenize(prompts, truncate=True)``, diffusion.py:136) and, with ``clip_model=ClipTextEncoder(...)``, the whole
     text -> label edge runs without the ``clip`` package.
-    ``low_latency``: serve small batches (up to 4096 token rows per sampler call: 8 images at 256 px) in the denoiser's low-latency capacity
-    class -- a one-image 35-step ``generate`` takes 39 ms instead of 54; larger batches then raise (use a second pipeline object for bulk work).
+    ``low_latency``: serve small batches in one of the denoiser's low-latency capacity classes (``Denoiser.set_low_latency``): ``True`` / ``1`` = up to 4096
+    token rows per sampler call (8 images at 256 px), ``2`` = up to 1024 (one or two images: one prompt per call) -- a one-image 35-step ``generate`` takes 36 /
+    33 ms instead of 50; larger batches then raise (use a second pipeline object for bulk work).
     """
 
     def __init__(self, cfg: LTDConfig, vae: Any = None, clip_model: Any = None, text_encoder=None,
-                 run_device: Optional[torch.device] = None, tokenizer: Any = None, low_latency: bool = False):
+                 run_device: Optional[torch.device] = None, tokenizer: Any = None, low_latency=False):
         dev = run_device if run_device is not None else device
         denoiser = Denoiser(**asdict(cfg.denoiser_cfg))
         denoiser = denoiser.to(cfg.denoiser_load.dtype)
         if low_latency:      # one-prompt-per-call serving (tld/app.py:48-65): the denoiser's small-batch capacity class (Denoiser.set_low_latency)
-            denoiser.set_low_latency(True)
+            denoiser.set_low_latency(low_latency)
         if cfg.denoiser_load.file_url is not None and cfg.denoiser_load.local_filename is not None:
             print(f"Downloading model from {cfg.denoiser_load.file_url}")
             download_file(cfg.denoiser_load.file_url, cfg.denoiser_load.local_filename)
