@@ -287,6 +287,32 @@ def test_split_k_gemm_slices_sum_to_the_product(M, N, K, ks):
     assert (c.double().sum(0) - full).abs().max().item() <= 4e-5 * full.abs().max().item() * np.sqrt(K / 64) + 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(512, 768, 3072, 8), (1024, 768, 3072, 4), (512, 384, 1536, 4)])
+def test_split_k_small_launch_kernel_bitwise_equals_8_wave_kernel(M, N, K, ks, tmp_path):
+    """Round 6: split-K launches with at most one 256 x 128 item per CU run on the 4-wave kernel of tld_updw.hip.  Its slices must be BITWISE those of the 8-wave
+    two-stage kernel (same K order per output element) -- the low-latency classes' numerics do not depend on which kernel a batch size selects.  TLD_SPLITK_SMALL
+    is read once per process: the 8-wave run is a subprocess."""
+    import ctypes as C
+    from transformer_latent_diffusion_amd import _lib
+    code = ("import sys, ctypes as C, numpy as np, torch\n"
+            "from transformer_latent_diffusion_amd import _lib\n"
+            f"M, N, K, ks = {M}, {N}, {K}, {ks}\n"
+            "g = torch.Generator().manual_seed(M + N + K + ks)\n"
+            "a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()\n"
+            "w = (torch.randn(N, K, generator=g) * 0.1).to(torch.bfloat16).cuda()\n"
+            "c = torch.full((ks, M, N), float('nan'), device='cuda', dtype=torch.float32)\n"
+            "_lib.check(_lib.lib().tld_debug_gemm_splitk(a.data_ptr(), w.data_ptr(), c.data_ptr(), M, N, K, ks, C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'splitk')\n"
+            "torch.cuda.synchronize(); np.save(sys.argv[1], c.cpu().numpy())\n")
+    outs = {}
+    for tag, env in (("small", {}), ("wave8", {"TLD_SPLITK_SMALL": "0"})):
+        path = tmp_path / f"{tag}.npy"
+        r = subprocess.run([sys.executable, "-c", code, str(path)], env=dict(os.environ, **env), capture_output=True, text=True,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(path)
+    assert np.isfinite(outs["small"]).all() and np.array_equal(outs["small"], outs["wave8"])
+
+
 def test_low_latency_class_vs_golden_and_inside_the_class():
     """Denoiser.set_low_latency (round 5; the reference serves one prompt per call, tld/app.py:48-65): split-K down projection for engines of at most
     4096 token rows.  Held against g5 exactly as the default class (forward, 35-step trajectory); bit-identical across batch sizes INSIDE the class;

@@ -1677,6 +1677,14 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
         static const bool small_on = !(getenv("TLD_UPDW_SMALL") && atoi(getenv("TLD_UPDW_SMALL")) == 0);
         if (small_on && updw_pp_supported(p) && (long)(p.M / 256) * (p.N / 128) <= device_cu_count()) { launch_updw_pp(p, s); return; }
     }
+    if (epilogue == EPI_F32 && p.ksplit > 1 && !p.f8 && !p.conv) {
+        // the low-latency classes' split-K down projection: one 256 x 128 x (K / splits) item per 4-wave workgroup while the launch has at most two items per CU
+        // (tld_updw.hip; the slices are bitwise those of the 8-wave two-stage kernel below).  TLD_SPLITK_SMALL=0: A/B and test hook.
+        static const bool sk_on = !(getenv("TLD_SPLITK_SMALL") && atoi(getenv("TLD_SPLITK_SMALL")) == 0);
+        // (two such workgroups fit a CU and, K loops only, share it well: eight images in class 1 -- 384 items -- 58.3 -> 48.8 ms per generate; the fused up-projection's epilogue does
+        // not: 288 - 480 tiles on two workgroups per CU measured 1 - 2 ms slower than the 8-wave kernel, hence one tile per CU there)
+        if (sk_on && splitk_pp_supported(p) && (long)(p.M / 256) * (p.N / 128) * p.ksplit <= 2L * device_cu_count()) { launch_splitk_pp(p, s); return; }
+    }
     int bn = choose_bn(p.M, p.N, epilogue, p.K);
     if (p.conv) {           // 256-wide tiles when the width allows and they fill the chip, else 128
         const long ntm = (p.M + 255) / 256;

@@ -49,6 +49,10 @@ template <int N> __device__ __forceinline__ void pp_wait_vmcnt() {
     else static_assert(N < 0, "unsupported vmcnt");
 }
 
+// MODE 0: EPI_UP_DWCONV2 (the fused depthwise epilogue).  MODE 1: EPI_F32 with GemmParams::ksplit -- the low-latency classes' split-K down projection: the tile list is
+// `ksplit` copies of the (m, n) grid, copy s multiplying the K range [s K, (s + 1) K) of both operands into fp32 slice s (c_f32 + s M ldc); same K order per output element as
+// gemm256p_kernel<128, EPI_F32>'s two-stage loop, so the slices are bitwise the same.
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nblocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -58,7 +62,9 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
 
     // ---- static schedule (gemm256p_kernel's): XCD x (= block id % 8) owns a contiguous run of the row-major tile order -- or, with xcd_ngroups = G, the cell
     // (tile-row block, tile-column group) of an (8 / G) x G grid -- and its workgroups take that run round-robin
-    const int ntn = p.N >> 7, ntm = p.M >> 8, ntiles = ntm * ntn;
+    const int ntn = p.N >> 7, ntm = p.M >> 8;
+    const int nsplit = (MODE == 1 && p.ksplit > 1) ? p.ksplit : 1;
+    const int ntiles = ntm * ntn * nsplit;
     const int bid = blockIdx.x, xcd = bid & 7, lidx = bid >> 3;
     const int per_xcd_blocks = (nblocks + 7 - xcd) / 8;
     const int G2 = p.xcd_ngroups > 1 ? p.xcd_ngroups : 1;
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
     const int xcount = G2 > 1 ? (r1 - r0) * gcols : q8 + (xcd < rr8 ? 1 : 0);
     const int my_tiles = lidx < xcount ? (xcount - lidx + per_xcd_blocks - 1) / per_xcd_blocks : 0;
     if (my_tiles == 0) return;
+    int sp_dec = 0;                                          // MODE 1: K-split of the tile tile_coords() decoded last
     auto tile_coords = [&](int i, int& m0, int& n0) {
         const int t = lidx + i * per_xcd_blocks;
         if (G2 > 1) {
@@ -76,7 +83,12 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
             m0 = (r0 + tm) << 8;
             n0 = (xn * gcols + (t - tm * gcols)) << 7;
         } else {
-            const int tile = xbase + t;
+            int tile = xbase + t;
+            if constexpr (MODE == 1) {
+                const int sp = tile / (ntm * ntn);
+                tile -= sp * (ntm * ntn);
+                sp_dec = sp;
+            }
             const int tm = tile / ntn;
             m0 = tm << 8;
             n0 = (tile - tm * ntn) << 7;
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
     };
 
     // zero pair-row (behind the ring: written once)
-    *reinterpret_cast<u32x4*>(smem + PP::ZROW + tid * 16) = u32x4{0u, 0u, 0u, 0u};
+    if constexpr (MODE == 0) *reinterpret_cast<u32x4*>(smem + PP::ZROW + tid * 16) = u32x4{0u, 0u, 0u, 0u};
 
     const int nk = p.K >> 6;                                 // 64-element K-tiles (even, >= 4: checked by the launcher)
     const unsigned lda2 = (unsigned)p.lda * 2u, ldw2 = (unsigned)p.ldw * 2u;
@@ -102,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
     for (int it = 0; it < my_tiles; ++it) {
         int m0, n0;
         tile_coords(it, m0, n0);
+        const size_t kb = (size_t)sp_dec * (size_t)p.K * 2;       // MODE 1: K byte offset of this tile's split (0 otherwise)
 
         // ---- DMA source offsets.  A half-tile h, piece q2 of this wave: image rows r = (wid 4 + q2) 8 + (lane >> 3) = tile rows (r >> 6) 128 + h 64 + (r & 63);
         // only the parity of q2 reaches the swizzle, everything else is a scalar offset: two registers per operand
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
 #pragma unroll
             for (int q2 = 0; q2 < 4; ++q2) {
                 if (q2 < lo || q2 >= hi_) continue;
-                const char* base = reinterpret_cast<const char*>(p.A) + (size_t)t * 128 + (size_t)(h * 64 + (q2 >> 1) * 16) * lda2;
+                const char* base = reinterpret_cast<const char*>(p.A) + kb + (size_t)t * 128 + (size_t)(h * 64 + (q2 >> 1) * 16) * lda2;
                 asm volatile("" : "+s"(base));
                 unsigned o = vA[q2 & 1];
                 asm volatile("" : "+v"(o));
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
         auto stageB = [&](int h, int t, int slot) {
 #pragma unroll
             for (int q2 = 0; q2 < 2; ++q2) {
-                const char* base = reinterpret_cast<const char*>(p.W) + (size_t)t * 128 + (size_t)(h * 32) * ldw2;
+                const char* base = reinterpret_cast<const char*>(p.W) + kb + (size_t)t * 128 + (size_t)(h * 32) * ldw2;
                 asm volatile("" : "+s"(base));
                 unsigned o = vB[q2];
                 asm volatile("" : "+v"(o));
@@ -156,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         // ---- prologue: side tables, K-tile 0 and the first half of K-tile 1 (all six slots)
+        if constexpr (MODE == 0) {
         if (p.row_stats && wid < 2) {
             const char* src = reinterpret_cast<const char*>(p.row_stats + m0) + wid * 1024 + lane * 16;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + PP::RS + wid * 1024), 16, 0, 0);
@@ -163,6 +177,7 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
         if ((wid == 3 || (wid == 2 && p.row_stats)) && lane < 32) {      // wave 2: c1, wave 3: bias of the tile's 128 columns
             const float* src = (wid == 2 ? p.ln_c1 : p.bias) + n0 + lane * 4;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(smem + PP::CB + (wid - 2) * 512), 16, 0, 0);
+        }
         }
         stageB(0, 0, 0); stageA(0, 0, 0, 0, 4); stageB(1, 0, 1); stageA(1, 0, 1, 0, 4); stageB(0, 1, 2); stageA(0, 1, 2, 0, 4);
         pp_wait_vmcnt<0>();
@@ -267,6 +282,24 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
         ktile(nk - 2, fb0, fb1, C1{});
         ktile(nk - 1, fb1, fb0, std::integral_constant<int, 2>{});
 
+        if constexpr (MODE == 1) {
+            // ---- fp32 slice of this split (natural MFMA order: a lane owns a column, a register quad four consecutive rows)
+            int tide = tid;
+            asm volatile("" : "+v"(tide));
+            const int l31 = tide & 31, hi = (tide >> 5) & 1;
+            float* cs = p.c_f32 + (size_t)sp_dec * p.M * p.ldc;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * 128 + i * 32 + 4 * hi + (r & 3) + 8 * (r >> 2);
+                        cs[(size_t)row * p.ldc + col] = acc[i][j][r];
+                    }
+                }
+        } else {
         // ---- epilogue (the arithmetic of gemm256p_kernel's EPI_UP_DWCONV2 branch on a 128-channel image): bf16(rstd (acc - mean c1) + bias) as token-pair dwords into
         // LDS, then the depthwise 3x3 + GELU from the image: a thread owns a channel quad and two adjacent image rows
         char* H = smem;
@@ -381,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
             ld(7, c2v); emit(c0v, c1v, c2v, 6);
             zero(c0v); emit(c1v, c2v, c0v, 7);
         }
+        }
         // every wave is done with the image before the next tile's operands overwrite it
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -396,14 +430,30 @@ bool updw_pp_supported(const GemmParams& p) {
 
 void launch_updw_pp(const GemmParams& p, hipStream_t s) {
     static PerDeviceOnce once;
-    once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(updw_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS); });
+    once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(updw_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PP::LDS); });
     const int ntn = p.N / 128, ntm = p.M / 256;
     const int ncu = device_cu_count();
     const int ntiles = ntm * ntn;
     const int nblocks = ntiles < 2 * ncu ? ntiles : 2 * ncu;           // (two workgroups fit a CU; launch_gemm only comes here with ntiles <= ncu)
     GemmParams pg = p;
     pg.xcd_ngroups = (ntn % 2 == 0 && ntm >= 8 && nblocks == 2 * ncu && ncu % 8 == 0) ? 2 : 0;
-    hipLaunchKernelGGL(updw_pp_kernel, dim3(nblocks), dim3(256), PP::LDS, s, pg, nblocks);
+    hipLaunchKernelGGL(updw_pp_kernel<0>, dim3(nblocks), dim3(256), PP::LDS, s, pg, nblocks);
+}
+
+// EPI_F32 with ksplit > 1 (the low-latency classes' down projection) on the same 4-wave K loop: K = the length of ONE split (a multiple of 128, >= 256)
+bool splitk_pp_supported(const GemmParams& p) {
+    return p.ksplit > 1 && p.c_f32 != nullptr && updw_pp_supported(p);
+}
+
+void launch_splitk_pp(const GemmParams& p, hipStream_t s) {
+    static PerDeviceOnce once;
+    once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(updw_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PP::RING_BYTES); });
+    const int ntiles = (p.N / 128) * (p.M / 256) * p.ksplit;
+    const int ncu = device_cu_count();
+    const int nblocks = ntiles < 2 * ncu ? ntiles : 2 * ncu;
+    GemmParams pg = p;
+    pg.xcd_ngroups = 0;
+    hipLaunchKernelGGL(updw_pp_kernel<1>, dim3(nblocks), dim3(256), PP::RING_BYTES, s, pg, nblocks);
 }
 
 }  // namespace tld
