@@ -313,6 +313,34 @@ def test_split_k_small_launch_kernel_bitwise_equals_8_wave_kernel(M, N, K, ks, t
     assert np.isfinite(outs["small"]).all() and np.array_equal(outs["small"], outs["wave8"])
 
 
+@pytest.mark.parametrize("batch", [2, 6, 32])
+def test_default_class_small_launch_down_projection_bitwise_equals_8_wave_kernel(batch, tmp_path):
+    """Round 6: the default class's down projection (x += hid Wdown^T + b and the LayerNorm-1 partial sums, tld/transformer_blocks.py:104,138) of launches with at most one
+    128 x 192 tile per CU runs on the 4-wave kernel of tld_updw.hip.  The forward output must be BITWISE that of the 8-wave 192- / 384-wide kernels -- the default class's
+    results do not depend on which kernel a batch size selects.  TLD_DOWN_SMALL is read once per process: the 8-wave run is a subprocess."""
+    code = ("import sys, numpy as np, torch\n"
+            "sys.path.insert(0, 'tests')\n"
+            "from dataclasses import asdict\n"
+            "from conftest import cfg_from_arr, load_golden, synth_weights\n"
+            "from transformer_latent_diffusion_amd import Denoiser\n"
+            "g = load_golden('g5_100m.npz'); cfg = cfg_from_arr(g['cfg'])\n"
+            "sd = synth_weights(cfg, g['weight_seed'], g['weight_checksum'])\n"
+            "m = Denoiser(**asdict(cfg)).to(torch.device('cuda', 0)); m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})\n"
+            f"B = {batch}; rng = np.random.default_rng(5); reps = -(-B // g['x'].shape[0])\n"
+            "x = np.concatenate([g['x']] * reps)[:B] * rng.uniform(0.7, 1.3, (B, 1, 1, 1)).astype(np.float32)\n"
+            "s = rng.uniform(0.05, 0.95, (B, 1)).astype(np.float32); lab = np.concatenate([g['label']] * reps)[:B]\n"
+            "t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()\n"
+            "np.save(sys.argv[1], m(t(x), t(s), t(lab)).float().cpu().numpy())\n")
+    outs = {}
+    for tag, env in (("small", {}), ("wave8", {"TLD_DOWN_SMALL": "0"})):
+        path = tmp_path / f"{tag}.npy"
+        r = subprocess.run([sys.executable, "-c", code, str(path)], env=dict(os.environ, **env), capture_output=True, text=True,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(path)
+    assert np.isfinite(outs["small"]).all() and np.abs(outs["small"]).max() > 0 and np.array_equal(outs["small"], outs["wave8"])
+
+
 def test_low_latency_class_vs_golden_and_inside_the_class():
     """Denoiser.set_low_latency (round 5; the reference serves one prompt per call, tld/app.py:48-65): split-K down projection for engines of at most
     4096 token rows.  Held against g5 exactly as the default class (forward, 35-step trajectory); bit-identical across batch sizes INSIDE the class;

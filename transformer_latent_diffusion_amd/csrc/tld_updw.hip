@@ -41,6 +41,7 @@ static_assert(2 * PP::LDS <= 160 * 1024, "two workgroups per CU");
 
 template <int N> __device__ __forceinline__ void pp_wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
@@ -421,6 +422,213 @@ __global__ __launch_bounds__(256, 2) void updw_pp_kernel(GemmParams p, int nbloc
     }
 }
 
+
+// =================================================================================================
+// EPI_BIAS_RESID (the MLP down projection, x += hid Wdown^T + b, + the LayerNorm-1 partial sums of the next block: tld/transformer_blocks.py:104,138) for SMALL launches of the
+// DEFAULT class: 128 x 192 tiles, 4 waves as 2 (M) x 2 (N) with the 64 x 96 wave tiles -- and, line by line, the per-wave epilogue -- of gemm256p_kernel<192, EPI_BIAS_RESID>.
+// At one image that kernel has 8 work items of 48 K-steps each (69 us per launch, half of a default-class step); here the same product is 16 items whose K loop needs no
+// partner wave: a 3-K-tile LDS ring (40 KiB per K-tile: A 128 rows + W 192 rows of 128 bytes), two phases per K-tile (k-slices 0-1 | 2-3: 12 MFMAs each), the fragments of the
+// next phase read during the MFMAs of the current one, one s_barrier per phase, K-tile t + 2 staged during K-tile t (vmcnt(4) at the one wait per K-tile).
+// Every output element is accumulated over K in the 8-wave kernel's order and finished by the same expressions: bitwise equal to it (tests/test_gpu_configs.py).
+struct DP {
+    static constexpr int A_BYTES = 128 * 128, B_BYTES = 192 * 128, KT_BYTES = A_BYTES + B_BYTES;      // one K-tile: 40 KiB
+    static constexpr int LDS = 3 * KT_BYTES;                                                            // 120 KiB
+    static constexpr int SCRATCH = 4608;                                                                // per-wave epilogue scratch (one 32 x 32 fp32 tile, 144-byte pitch)
+};
+
+__global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nblocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int ntn = p.N / 192, ntm = p.M >> 7, ntiles = ntm * ntn;
+    const int nk = p.K >> 6;                                 // 64-element K-tiles (>= 3)
+    const unsigned lda2 = (unsigned)p.lda * 2u, ldw2 = (unsigned)p.ldw * 2u;
+    unsigned ra0, rb0;
+    {
+        int l31v = lane & 31, hiv = lane >> 5;
+        asm volatile("" : "+v"(l31v), "+v"(hiv));
+        const int sw = (l31v >> 1) & 7;
+        ra0 = (unsigned)((wm * 64 + l31v) * 128 + ((hiv ^ sw) << 4));
+        rb0 = (unsigned)(DP::A_BYTES + (wn * 96 + l31v) * 128 + ((hiv ^ sw) << 4));
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += nblocks) {
+        const int tm = tile / ntn;
+        const int m0 = tm << 7, n0 = (tile - tm * ntn) * 192;
+        // DMA source offsets: piece q of this wave = image rows (wid 4 + q) 8 + (lane >> 3) of A (4 pieces), (wid 6 + q) 8 + (lane >> 3) of W (6 pieces); only the parity of q
+        // reaches the swizzle, the rest is a scalar row offset
+        unsigned vA[2], vB[2];
+        {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int r = (wid * 4 + o) * 8 + (ln >> 3);
+                unsigned va = __umul24((unsigned)(m0 + r), lda2) + (unsigned)(((ln & 7) ^ ((r >> 1) & 7)) * 16);
+                const int rb_ = (wid * 6 + o) * 8 + (ln >> 3);
+                unsigned vb = __umul24((unsigned)(n0 + rb_), ldw2) + (unsigned)(((ln & 7) ^ ((rb_ >> 1) & 7)) * 16);
+                asm volatile("" : "+v"(va), "+v"(vb));
+                vA[o] = va; vB[o] = vb;
+            }
+        }
+        auto stageA = [&](int t, int slot, int lo, int hi_) {
+#pragma unroll
+            for (int q2 = 0; q2 < 4; ++q2) {
+                if (q2 < lo || q2 >= hi_) continue;
+                const char* base = reinterpret_cast<const char*>(p.A) + (size_t)t * 128 + (size_t)((q2 >> 1) * 16) * lda2;
+                asm volatile("" : "+s"(base));
+                unsigned o = vA[q2 & 1];
+                asm volatile("" : "+v"(o));
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + o), (lptr_t)(smem + slot * DP::KT_BYTES + (wid * 4 + q2) * 1024), 16, 0, 0);
+            }
+        };
+        auto stageB = [&](int t, int slot, int lo, int hi_) {
+#pragma unroll
+            for (int q2 = 0; q2 < 6; ++q2) {
+                if (q2 < lo || q2 >= hi_) continue;
+                const char* base = reinterpret_cast<const char*>(p.W) + (size_t)t * 128 + (size_t)((q2 >> 1) * 16) * ldw2;
+                asm volatile("" : "+s"(base));
+                unsigned o = vB[q2 & 1];
+                asm volatile("" : "+v"(o));
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + o), (lptr_t)(smem + slot * DP::KT_BYTES + DP::A_BYTES + (wid * 6 + q2) * 1024), 16, 0, 0);
+            }
+        };
+        f32x16 acc[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // fragments of one phase: k-slices 2 h, 2 h + 1 of a K-tile -- A [row tile][k-slice of the pair], W [column tile][k-slice of the pair]
+        bf16x8 fa[2][2][2], fb[2][3][2];                      // [buffer][tile][k-slice of the pair]
+        auto read_frags = [&](auto bufc, int slot, int h) {
+            constexpr int bf = decltype(bufc)::value;
+            const unsigned base = (unsigned)(slot * DP::KT_BYTES);
+            unsigned a = ra0, b = rb0;
+            asm volatile("" : "+v"(a), "+v"(b));
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const unsigned kx = (unsigned)((2 * h + kk) << 5);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[bf][i][kk] = *reinterpret_cast<const bf16x8*>(smem + ((a ^ kx) + base) + i * 4096);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) fb[bf][j][kk] = *reinterpret_cast<const bf16x8*>(smem + ((b ^ kx) + base) + j * 4096);
+            }
+        };
+        // swapped operand order (a lane owns a token row, a register quad four consecutive columns), as the 8-wave kernel; side(g) = the fragment reads / DMA pieces issued
+        // after MFMA group g (3 MFMAs), pinned in this order so that their issue time hides under the matrix pipe
+        auto mma = [&](auto bufc, auto&& side) {
+            constexpr int bf = decltype(bufc)::value;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[bf][j][kk], fa[bf][i][kk], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    side(kk * 2 + i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        };
+        using B0 = std::integral_constant<int, 0>; using B1 = std::integral_constant<int, 1>;
+        auto slot3 = [](int k) { return k - (k / 3) * 3; };
+
+        // ---- prologue: K-tiles 0 and 1
+        stageA(0, 0, 0, 4); stageB(0, 0, 0, 6); stageA(1, 1, 0, 4); stageB(1, 1, 0, 6);
+        pp_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        read_frags(B0{}, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int t = 0; t < nk; ++t) {
+            const int s0 = slot3(t), s1 = slot3(t + 1), s2 = slot3(t + 2);
+            const bool st = t + 2 < nk;
+            // phase 0: k-slices 0, 1 of K-tile t from buffer 0; read k-slices 2, 3 into buffer 1; stage A of K-tile t + 2 (its slot held K-tile t - 1, whose reads ended a phase ago)
+            mma(B0{}, [&](int g) {
+                if (g == 0) read_frags(B1{}, s0, 1);
+                if (st && g == 1) stageA(t + 2, s2, 0, 2);
+                if (st && g == 2) stageA(t + 2, s2, 2, 4);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (st) pp_wait_vmcnt<4>(); else pp_wait_vmcnt<0>();          // K-tile t + 1 has landed (own pieces) ...
+            __builtin_amdgcn_s_barrier();                                  // ... everybody's
+            // phase 1: k-slices 2, 3 from buffer 1; read k-slices 0, 1 of K-tile t + 1 into buffer 0; stage W of K-tile t + 2
+            mma(B1{}, [&](int g) {
+                if (g == 0 && t + 1 < nk) read_frags(B0{}, s1, 0);
+                if (st && g == 1) stageB(t + 2, s2, 0, 2);
+                if (st && g == 2) stageB(t + 2, s2, 2, 4);
+                if (st && g == 3) stageB(t + 2, s2, 4, 6);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+
+        // ---- epilogue: gemm256p_kernel's EPI_BIAS_RESID branch for a 64 x 96 wave tile (G::TM = 2, G::TN = 3, G::WCOLS = 96)
+        int lanev = lane;
+        asm volatile("" : "+v"(lanev));
+        const int l31 = lanev & 31, hi = lanev >> 5;
+        char* ws = smem + wid * DP::SCRATCH;
+        const int row0 = m0 + wm * 64, col0 = n0 + wn * 96;
+        constexpr int P = 32 * 4 + 16;
+        resid4_t rnx[4];
+        auto rfetch1 = [&](int i2, int j2, int itr) {
+            const int idx = itr * 64 + lanev;
+            const int row = row0 + i2 * 32 + (idx >> 3), col = col0 + j2 * 32 + (idx & 7) * 4;
+            rnx[itr] = rs_raw4(p.resid + (size_t)row * p.ldr + col);
+        };
+#pragma unroll
+        for (int itr = 0; itr < 4; ++itr) rfetch1(0, 0, itr);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int cl = 8 * rq + 4 * hi;
+                    const float4 bv = *reinterpret_cast<const float4*>(p.bias + col0 + j * 32 + cl);
+                    float4 v;
+                    v.x = acc[i][j][rq * 4 + 0] + bv.x; v.y = acc[i][j][rq * 4 + 1] + bv.y;
+                    v.z = acc[i][j][rq * 4 + 2] + bv.z; v.w = acc[i][j][rq * 4 + 3] + bv.w;
+                    *reinterpret_cast<float4*>(ws + l31 * P + cl * 4) = v;
+                }
+#pragma unroll
+                for (int itr = 0; itr < 4; ++itr) {
+                    const int idx = itr * 64 + lanev;
+                    const int rl = idx >> 3, ch = idx & 7;
+                    const float4 v = *reinterpret_cast<const float4*>(ws + rl * P + ch * 16);
+                    const int row = row0 + i * 32 + rl, col = col0 + j * 32 + ch * 4;
+                    resid_t* px = p.resid + (size_t)row * p.ldr + col;
+                    float4 o = rs_widen4(rnx[itr]);
+                    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                    rs_store4(px, o);
+                    const float r0 = rs_round(o.x), r1 = rs_round(o.y), r2 = rs_round(o.z), r3 = rs_round(o.w);
+                    ps[itr] += (r0 + r1) + (r2 + r3);
+                    pq[itr] = fmaf(r0, r0, fmaf(r1, r1, fmaf(r2, r2, fmaf(r3, r3, pq[itr]))));
+                    if (j + 1 < 3) rfetch1(i, j + 1, itr); else if (i + 1 < 2) rfetch1(i + 1, 0, itr);
+                }
+            }
+            if (p.stats_out) {
+                const int slot = col0 / 96;
+#pragma unroll
+                for (int itr = 0; itr < 4; ++itr) {
+                    float a = ps[itr], q2 = pq[itr];
+                    a = dpp_add<0xB1>(a); q2 = dpp_add<0xB1>(q2);
+                    a = dpp_add<0x4E>(a); q2 = dpp_add<0x4E>(q2);
+                    a = dpp_add<0x141>(a); q2 = dpp_add<0x141>(q2);
+                    const int row = row0 + i * 32 + itr * 8 + (lanev >> 3);
+                    if ((lanev & 7) == 0 && slot < kLnSlots) p.stats_out[(size_t)row * kLnSlots + slot] = make_float2(a, q2);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // every wave is done with its scratch before the next tile's operands arrive
+    }
+}
+
 }  // namespace
 
 bool updw_pp_supported(const GemmParams& p) {
@@ -454,6 +662,21 @@ void launch_splitk_pp(const GemmParams& p, hipStream_t s) {
     GemmParams pg = p;
     pg.xcd_ngroups = 0;
     hipLaunchKernelGGL(updw_pp_kernel<1>, dim3(nblocks), dim3(256), PP::RING_BYTES, s, pg, nblocks);
+}
+
+// EPI_BIAS_RESID of the default class (bf16 operands, no conv) on 128 x 192 tiles: M % 128 == 0, N % 192 == 0, K % 64 == 0, K >= 192
+bool down_pp_supported(const GemmParams& p) {
+    return !p.f8 && !p.conv && !p.w_batch_rows && p.ksplit <= 1 && p.M % 128 == 0 && p.N % 192 == 0 && p.K % 64 == 0 && p.K >= 192 && p.ldr % 4 == 0 && p.bias && p.resid &&
+           (size_t)p.M * p.lda * 2 < ((size_t)1 << 32) && (size_t)p.N * p.ldw * 2 < ((size_t)1 << 32) && (unsigned)p.lda * 2u < (1u << 24) && (unsigned)p.ldw * 2u < (1u << 24);
+}
+
+void launch_down_pp(const GemmParams& p, hipStream_t s) {
+    static PerDeviceOnce once;
+    once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(down_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DP::LDS); });
+    const int ntiles = (p.M / 128) * (p.N / 192);
+    const int ncu = device_cu_count();
+    const int nblocks = ntiles < ncu ? ntiles : ncu;
+    hipLaunchKernelGGL(down_pp_kernel, dim3(nblocks), dim3(256), DP::LDS, s, p, nblocks);
 }
 
 }  // namespace tld
