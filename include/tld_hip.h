@@ -79,7 +79,7 @@ TLD_API int tld_engine_set_gemm_dtype(tld_engine* e, int32_t dtype);
  *   on = 1: four K-splits, engines of at most 4096 token rows (max_batch x tokens; e.g. 8 images = 16 CFG-doubled samples at 256 px)
  *   on = 2: eight K-splits, engines of at most 1024 token rows (one or two images per CFG call at 256 px -- the one-prompt-per-call pattern)
  *   on = 0: the default class
- * A one-image 35-step generate takes 39 ms in the default class, 31 ms in class 1, 30 ms in class 2; eight images 46 ms in either.  Results of a class differ from
+ * A one-image 35-step generate takes 37 ms in the default class, 31 ms in class 1, 30 ms in class 2; eight images 46 ms in either.  Results of a class differ from
  * the default class (and from the other class) in the fp32 summation order of that product (same tolerances against the reference); a class is chosen by the CALLER for the engine,
  * never by the batch of a call: inside a class results are bit-identical across batch sizes.
  * May be called any time after tld_engine_create; fails (TLD_ERR_INVALID) on larger engines, on widths other than 384 / 768, on hidden widths that do not split

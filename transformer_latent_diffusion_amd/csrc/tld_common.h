@@ -404,6 +404,7 @@ void launch_updw_pp(const GemmParams& p, hipStream_t s);
 bool splitk_pp_supported(const GemmParams& p);          // EPI_F32 with ksplit > 1 on the same 4-wave K loop (bitwise the slices of gemm256p_kernel<128, EPI_F32>)
 void launch_splitk_pp(const GemmParams& p, hipStream_t s);
 bool down_pp_supported(const GemmParams& p);            // EPI_BIAS_RESID (default class) on 128 x 192 tiles with 4-wave workgroups: bitwise gemm256p_kernel<192 | 384, EPI_BIAS_RESID>
+bool down_pp_fits(const GemmParams& p);                 // ... at most one 64- or 128-row tile per CU
 void launch_down_pp(const GemmParams& p, hipStream_t s);
 // the two rows on either side of every tile seam of a 32 x 32 image (dw_grid = 32): depthwise 3x3 + GELU on the seam rows the fused epilogue left
 void launch_dwconv_seam(const uint32_t* seam, const uint32_t* dw_wpk, const float* dw_b_half, bf16* out, int ldo, int batch, int channels, hipStream_t s);

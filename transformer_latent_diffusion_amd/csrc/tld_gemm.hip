@@ -1686,10 +1686,10 @@ void launch_gemm(const GemmParams& p_in, int epilogue, hipStream_t s) {
         if (sk_on && splitk_pp_supported(p) && (long)(p.M / 256) * (p.N / 128) * p.ksplit <= 2L * device_cu_count()) { launch_splitk_pp(p, s); return; }
     }
     if (epilogue == EPI_BIAS_RESID && !p.f8 && !p.conv) {
-        // the default class's down projection at small batch: 128 x 192 tiles on 4-wave workgroups while the launch has at most one tile per CU (tld_updw.hip; bitwise the
+        // the default class's down projection at small batch: 64 x 192 or 128 x 192 tiles on 4-wave workgroups while the launch has at most one tile per CU (tld_updw.hip; bitwise the
         // 8-wave 192- / 384-wide kernels below).  TLD_DOWN_SMALL=0: A/B and test hook.
         static const bool dn_on = !(getenv("TLD_DOWN_SMALL") && atoi(getenv("TLD_DOWN_SMALL")) == 0);
-        if (dn_on && down_pp_supported(p) && (long)(p.M / 128) * (p.N / 192) <= device_cu_count()) { launch_down_pp(p, s); return; }
+        if (dn_on && down_pp_supported(p) && down_pp_fits(p)) { launch_down_pp(p, s); return; }
     }
     int bn = choose_bn(p.M, p.N, epilogue, p.K);
     if (p.conv) {           // 256-wide tiles when the width allows and they fill the chip, else 128

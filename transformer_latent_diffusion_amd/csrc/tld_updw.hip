@@ -41,6 +41,7 @@ static_assert(2 * PP::LDS <= 160 * 1024, "two workgroups per CU");
 
 template <int N> __device__ __forceinline__ void pp_wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -436,13 +437,16 @@ struct DP {
     static constexpr int SCRATCH = 4608;                                                                // per-wave epilogue scratch (one 32 x 32 fp32 tile, 144-byte pitch)
 };
 
+// TM = 32-row MFMA tiles per wave: 2 = 128 x 192 tiles (64 x 96 wave tiles), 1 = 64 x 192 tiles (32 x 96): twice the work items of half the K-tile time while they still fit one per CU
+template <int TM>
 __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nblocks) {
+    constexpr int BM = 64 * TM, NA = 2 * TM;                 // tile rows; A pieces (8 rows each) per wave and K-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
-    const int ntn = p.N / 192, ntm = p.M >> 7, ntiles = ntm * ntn;
+    const int ntn = p.N / 192, ntm = p.M / BM, ntiles = ntm * ntn;
     const int nk = p.K >> 6;                                 // 64-element K-tiles (>= 3)
     const unsigned lda2 = (unsigned)p.lda * 2u, ldw2 = (unsigned)p.ldw * 2u;
     unsigned ra0, rb0;
@@ -450,13 +454,13 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
         int l31v = lane & 31, hiv = lane >> 5;
         asm volatile("" : "+v"(l31v), "+v"(hiv));
         const int sw = (l31v >> 1) & 7;
-        ra0 = (unsigned)((wm * 64 + l31v) * 128 + ((hiv ^ sw) << 4));
+        ra0 = (unsigned)((wm * 32 * TM + l31v) * 128 + ((hiv ^ sw) << 4));
         rb0 = (unsigned)(DP::A_BYTES + (wn * 96 + l31v) * 128 + ((hiv ^ sw) << 4));
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += nblocks) {
         const int tm = tile / ntn;
-        const int m0 = tm << 7, n0 = (tile - tm * ntn) * 192;
-        // DMA source offsets: piece q of this wave = image rows (wid 4 + q) 8 + (lane >> 3) of A (4 pieces), (wid 6 + q) 8 + (lane >> 3) of W (6 pieces); only the parity of q
+        const int m0 = tm * BM, n0 = (tile - tm * ntn) * 192;
+        // DMA source offsets: piece q of this wave = image rows (wid NA + q) 8 + (lane >> 3) of A (NA pieces), (wid 6 + q) 8 + (lane >> 3) of W (6 pieces); only the parity of q
         // reaches the swizzle, the rest is a scalar row offset
         unsigned vA[2], vB[2];
         {
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
             asm volatile("" : "+v"(ln));
 #pragma unroll
             for (int o = 0; o < 2; ++o) {
-                const int r = (wid * 4 + o) * 8 + (ln >> 3);
+                const int r = (wid * NA + o) * 8 + (ln >> 3);
                 unsigned va = __umul24((unsigned)(m0 + r), lda2) + (unsigned)(((ln & 7) ^ ((r >> 1) & 7)) * 16);
                 const int rb_ = (wid * 6 + o) * 8 + (ln >> 3);
                 unsigned vb = __umul24((unsigned)(n0 + rb_), ldw2) + (unsigned)(((ln & 7) ^ ((rb_ >> 1) & 7)) * 16);
@@ -474,13 +478,13 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
         }
         auto stageA = [&](int t, int slot, int lo, int hi_) {
 #pragma unroll
-            for (int q2 = 0; q2 < 4; ++q2) {
+            for (int q2 = 0; q2 < NA; ++q2) {
                 if (q2 < lo || q2 >= hi_) continue;
                 const char* base = reinterpret_cast<const char*>(p.A) + (size_t)t * 128 + (size_t)((q2 >> 1) * 16) * lda2;
                 asm volatile("" : "+s"(base));
                 unsigned o = vA[q2 & 1];
                 asm volatile("" : "+v"(o));
-                __builtin_amdgcn_global_load_lds((gptr_t)(base + o), (lptr_t)(smem + slot * DP::KT_BYTES + (wid * 4 + q2) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(base + o), (lptr_t)(smem + slot * DP::KT_BYTES + (wid * NA + q2) * 1024), 16, 0, 0);
             }
         };
         auto stageB = [&](int t, int slot, int lo, int hi_) {
@@ -494,16 +498,16 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
                 __builtin_amdgcn_global_load_lds((gptr_t)(base + o), (lptr_t)(smem + slot * DP::KT_BYTES + DP::A_BYTES + (wid * 6 + q2) * 1024), 16, 0, 0);
             }
         };
-        f32x16 acc[2][3];
+        f32x16 acc[TM][3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         // fragments of one phase: k-slices 2 h, 2 h + 1 of a K-tile -- A [row tile][k-slice of the pair], W [column tile][k-slice of the pair]
-        bf16x8 fa[2][2][2], fb[2][3][2];                      // [buffer][tile][k-slice of the pair]
+        bf16x8 fa[2][TM][2], fb[2][3][2];                      // [buffer][tile][k-slice of the pair]
         auto read_frags = [&](auto bufc, int slot, int h) {
             constexpr int bf = decltype(bufc)::value;
             const unsigned base = (unsigned)(slot * DP::KT_BYTES);
@@ -513,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
             for (int kk = 0; kk < 2; ++kk) {
                 const unsigned kx = (unsigned)((2 * h + kk) << 5);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[bf][i][kk] = *reinterpret_cast<const bf16x8*>(smem + ((a ^ kx) + base) + i * 4096);
+                for (int i = 0; i < TM; ++i) fa[bf][i][kk] = *reinterpret_cast<const bf16x8*>(smem + ((a ^ kx) + base) + i * 4096);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) fb[bf][j][kk] = *reinterpret_cast<const bf16x8*>(smem + ((b ^ kx) + base) + j * 4096);
             }
@@ -525,12 +529,12 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < TM; ++i) {
 #pragma unroll
                     for (int j = 0; j < 3; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[bf][j][kk], fa[bf][i][kk], acc[i][j], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    side(kk * 2 + i);
+                    side(kk * TM + i);
                     __builtin_amdgcn_sched_barrier(0);
                 }
         };
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
         auto slot3 = [](int k) { return k - (k / 3) * 3; };
 
         // ---- prologue: K-tiles 0 and 1
-        stageA(0, 0, 0, 4); stageB(0, 0, 0, 6); stageA(1, 1, 0, 4); stageB(1, 1, 0, 6);
+        stageA(0, 0, 0, NA); stageB(0, 0, 0, 6); stageA(1, 1, 0, NA); stageB(1, 1, 0, 6);
         pp_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         read_frags(B0{}, 0, 0);
@@ -547,20 +551,25 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
             const int s0 = slot3(t), s1 = slot3(t + 1), s2 = slot3(t + 2);
             const bool st = t + 2 < nk;
             // phase 0: k-slices 0, 1 of K-tile t from buffer 0; read k-slices 2, 3 into buffer 1; stage A of K-tile t + 2 (its slot held K-tile t - 1, whose reads ended a phase ago)
-            mma(B0{}, [&](int g) {
+            mma(B0{}, [&](int g) {                          // (2 TM groups of 3 MFMAs per phase)
                 if (g == 0) read_frags(B1{}, s0, 1);
                 if (st && g == 1) stageA(t + 2, s2, 0, 2);
-                if (st && g == 2) stageA(t + 2, s2, 2, 4);
+                if (st && TM == 2 && g == 2) stageA(t + 2, s2, 2, 4);
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (st) pp_wait_vmcnt<4>(); else pp_wait_vmcnt<0>();          // K-tile t + 1 has landed (own pieces) ...
+            if (st) pp_wait_vmcnt<NA>(); else pp_wait_vmcnt<0>();          // K-tile t + 1 has landed (own pieces) ...
             __builtin_amdgcn_s_barrier();                                  // ... everybody's
             // phase 1: k-slices 2, 3 from buffer 1; read k-slices 0, 1 of K-tile t + 1 into buffer 0; stage W of K-tile t + 2
             mma(B1{}, [&](int g) {
                 if (g == 0 && t + 1 < nk) read_frags(B0{}, s1, 0);
-                if (st && g == 1) stageB(t + 2, s2, 0, 2);
-                if (st && g == 2) stageB(t + 2, s2, 2, 4);
-                if (st && g == 3) stageB(t + 2, s2, 4, 6);
+                if constexpr (TM == 2) {
+                    if (st && g == 1) stageB(t + 2, s2, 0, 2);
+                    if (st && g == 2) stageB(t + 2, s2, 2, 4);
+                    if (st && g == 3) stageB(t + 2, s2, 4, 6);
+                } else {
+                    if (st && g == 0) stageB(t + 2, s2, 0, 3);
+                    if (st && g == 1) stageB(t + 2, s2, 3, 6);
+                }
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
         asm volatile("" : "+v"(lanev));
         const int l31 = lanev & 31, hi = lanev >> 5;
         char* ws = smem + wid * DP::SCRATCH;
-        const int row0 = m0 + wm * 64, col0 = n0 + wn * 96;
+        const int row0 = m0 + wm * 32 * TM, col0 = n0 + wn * 96;
         constexpr int P = 32 * 4 + 16;
         resid4_t rnx[4];
         auto rfetch1 = [&](int i2, int j2, int itr) {
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
 #pragma unroll
         for (int itr = 0; itr < 4; ++itr) rfetch1(0, 0, itr);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
             float ps[4] = {0.f, 0.f, 0.f, 0.f}, pq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -608,7 +617,7 @@ __global__ __launch_bounds__(256, 2) void down_pp_kernel(GemmParams p, int nbloc
                     const float r0 = rs_round(o.x), r1 = rs_round(o.y), r2 = rs_round(o.z), r3 = rs_round(o.w);
                     ps[itr] += (r0 + r1) + (r2 + r3);
                     pq[itr] = fmaf(r0, r0, fmaf(r1, r1, fmaf(r2, r2, fmaf(r3, r3, pq[itr]))));
-                    if (j + 1 < 3) rfetch1(i, j + 1, itr); else if (i + 1 < 2) rfetch1(i + 1, 0, itr);
+                    if (j + 1 < 3) rfetch1(i, j + 1, itr); else if (i + 1 < TM) rfetch1(i + 1, 0, itr);
                 }
             }
             if (p.stats_out) {
@@ -664,19 +673,31 @@ void launch_splitk_pp(const GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL(updw_pp_kernel<1>, dim3(nblocks), dim3(256), PP::RING_BYTES, s, pg, nblocks);
 }
 
-// EPI_BIAS_RESID of the default class (bf16 operands, no conv) on 128 x 192 tiles: M % 128 == 0, N % 192 == 0, K % 64 == 0, K >= 192
+// EPI_BIAS_RESID of the default class (bf16 operands, no conv) on 64 x 192 or 128 x 192 tiles: M % 64 == 0, N % 192 == 0, K % 64 == 0, K >= 192
 bool down_pp_supported(const GemmParams& p) {
-    return !p.f8 && !p.conv && !p.w_batch_rows && p.ksplit <= 1 && p.M % 128 == 0 && p.N % 192 == 0 && p.K % 64 == 0 && p.K >= 192 && p.ldr % 4 == 0 && p.bias && p.resid &&
+    return !p.f8 && !p.conv && !p.w_batch_rows && p.ksplit <= 1 && p.M % 64 == 0 && p.N % 192 == 0 && p.K % 64 == 0 && p.K >= 192 && p.ldr % 4 == 0 && p.bias && p.resid &&
            (size_t)p.M * p.lda * 2 < ((size_t)1 << 32) && (size_t)p.N * p.ldw * 2 < ((size_t)1 << 32) && (unsigned)p.lda * 2u < (1u << 24) && (unsigned)p.ldw * 2u < (1u << 24);
+}
+
+// largest launch this form takes: one 128 x 192 tile per CU
+bool down_pp_fits(const GemmParams& p) {
+    const long ncu = device_cu_count();
+    return (long)(p.M / 64) * (p.N / 192) <= ncu || (p.M % 128 == 0 && (long)(p.M / 128) * (p.N / 192) <= ncu);
 }
 
 void launch_down_pp(const GemmParams& p, hipStream_t s) {
     static PerDeviceOnce once;
-    once.run([&] { hipFuncSetAttribute(reinterpret_cast<const void*>(down_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DP::LDS); });
-    const int ntiles = (p.M / 128) * (p.N / 192);
+    once.run([&] {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(down_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, DP::LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(down_pp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, DP::LDS);
+    });
     const int ncu = device_cu_count();
-    const int nblocks = ntiles < ncu ? ntiles : ncu;
-    hipLaunchKernelGGL(down_pp_kernel, dim3(nblocks), dim3(256), DP::LDS, s, p, nblocks);
+    const int n64 = (p.M / 64) * (p.N / 192);
+    if (n64 <= ncu) hipLaunchKernelGGL(down_pp_kernel<1>, dim3(n64), dim3(256), DP::LDS, s, p, n64);       // 64-row tiles while they fit one per CU
+    else {
+        const int n128 = (p.M / 128) * (p.N / 192);
+        hipLaunchKernelGGL(down_pp_kernel<2>, dim3(n128 < ncu ? n128 : ncu), dim3(256), DP::LDS, s, p, n128 < ncu ? n128 : ncu);
+    }
 }
 
 }  // namespace tld

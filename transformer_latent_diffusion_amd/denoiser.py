@@ -177,7 +177,7 @@ class Denoiser:
 
     def set_low_latency(self, on=True) -> "Denoiser":
         """Serve SMALL batches in a low-latency capacity class (``tld_engine_set_low_latency``): the MLP down projection of every block runs as
-        split-K, which cuts a one-image 35-step ``generate`` from ~39 ms to ~31 ms (``True`` / ``1``: four K-splits, up to ``LOW_LATENCY_MAX_ROWS``
+        split-K, which cuts a one-image 35-step ``generate`` from ~37 ms to ~31 ms (``True`` / ``1``: four K-splits, up to ``LOW_LATENCY_MAX_ROWS``
         token rows = 8 images at 256 px) or ~30 ms (``2``: eight K-splits, up to ``LOW_LATENCY_MAX_ROWS_SINGLE`` = one or two images per call --
         the reference's serving pattern, one prompt per call, tld/app.py:48-65).  A class is a property of this model object, not of a call: every
         engine it builds is in the class, results inside it are bit-identical across batch sizes, and they differ from the default class (and from

@@ -137,7 +137,7 @@ class DiffusionTransformer:
     text -> label edge runs without the ``clip`` package.
     ``low_latency``: serve small batches in one of the denoiser's low-latency capacity classes (``Denoiser.set_low_latency``): ``True`` / ``1`` = up to 4096
     token rows per sampler call (8 images at 256 px), ``2`` = up to 1024 (one or two images: one prompt per call) -- a one-image 35-step ``generate`` takes 31 /
-    30 ms instead of 39; larger batches then raise (use a second pipeline object for bulk work).
+    30 ms instead of 37; larger batches then raise (use a second pipeline object for bulk work).
     """
 
     def __init__(self, cfg: LTDConfig, vae: Any = None, clip_model: Any = None, text_encoder=None,
